@@ -1,0 +1,87 @@
+"""ctypes binding of ``libhgvae_hip.so`` (the C ABI declared in ``include/hgvae_hip.h``).
+
+The shared library is built in-tree (``hgvae_amd/csrc/Makefile``).  There is no
+fallback: if it is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhgvae_hip.so")
+
+_vp, _i64, _i32, _f32, _u64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol of include/hgvae_hip.h
+SIGNATURES = {
+    "hgv_version": (C.c_int, []),
+    "hgv_last_error": (C.c_char_p, []),
+    "hgv_csr_build_ws": (_sz, [_i64, _i64]),
+    "hgv_csr_build": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hgv_sort_pairs_ws": (_sz, [_i64]),
+    "hgv_sort_pairs_u32": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "hgv_agg_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "hgv_agg_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "hgv_bn_act_ws": (_sz, [_i64, _i32]),
+    "hgv_bn_act_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _f32, _vp, _vp, _f32,
+                                 _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "hgv_bn_act_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),
+    "hgv_bn_act_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _vp,
+                                 _i64, _vp, _vp, _vp, _sz, _vp]),
+    "hgv_loss_ws": (_sz, []),
+    "hgv_reparam_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _u64, _u64, _vp, _i64, _vp, _vp]),
+    "hgv_reparam_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "hgv_kl_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "hgv_kl_bwd": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
+    "hgv_mse_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
+    "hgv_mse_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+}
+
+_lib = None
+
+
+class HgvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library once; raise if the built artefact is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HgvError(
+            f"{LIB_PATH} not found: build it with `make -C hgvae_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HgvError(f"{name} failed ({rc}): {lib.hgv_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HgvError("hgvae_amd operators run on the GPU only (got a CPU tensor); there is no CPU fallback")

@@ -1,0 +1,197 @@
+// Neighbour aggregation over a CSR: out[i,:] = rs_i * sum_{k in row i} w_k * x[col[k],:] (+ add[i,:]).
+//
+// Replaces PyG's index_select -> scatter_add_ -> count -> divide sequence behind
+// SAGEConv / GraphConv / GCNConv / GATConv (reference call sites
+// gvae/gvae_skipcon.py:105-118, gvae/gvae_skipcon_attention.py:109,
+// autoencoder/vae_with_pool.py:39) and, run on the transposed CSR, its autograd.
+//
+// Mapping: a group of L lanes (L = power of two <= 64) owns one destination row; lane l
+// of the group owns feature chunks l, l+L, ... (VEC floats each, 16-byte loads when the
+// layout allows).  The row's segment is walked in order, so the unweighted sum is
+// bit-identical to a sequential scatter_add_ in stable edge order.  No atomics, no
+// cross-lane reduction: every output element has exactly one writer.
+// Column indices are fetched L at a time with one coalesced load and broadcast with
+// ds_bpermute (__shfl), so the dependent col -> row-address chain is paid once per L edges.
+#include "common.h"
+
+namespace {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { using T = float; };
+template <> struct VecT<2> { using T = float2; };
+template <> struct VecT<4> { using T = float4; };
+
+template <int VEC> __device__ __forceinline__ void vzero(typename VecT<VEC>::T& a);
+template <> __device__ __forceinline__ void vzero<1>(float& a) { a = 0.f; }
+template <> __device__ __forceinline__ void vzero<2>(float2& a) { a = make_float2(0.f, 0.f); }
+template <> __device__ __forceinline__ void vzero<4>(float4& a) { a = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// acc += v            (unweighted: plain adds, bit-faithful to scatter_add_)
+__device__ __forceinline__ void vadd(float& a, const float& v) { a = __fadd_rn(a, v); }
+__device__ __forceinline__ void vadd(float2& a, const float2& v) { a.x = __fadd_rn(a.x, v.x); a.y = __fadd_rn(a.y, v.y); }
+__device__ __forceinline__ void vadd(float4& a, const float4& v) {
+    a.x = __fadd_rn(a.x, v.x); a.y = __fadd_rn(a.y, v.y); a.z = __fadd_rn(a.z, v.z); a.w = __fadd_rn(a.w, v.w);
+}
+// acc += w * v        (product rounded, then added: the order PyG's message * alpha -> scatter_add_ uses)
+__device__ __forceinline__ void vmad(float& a, float w, const float& v) { a = __fadd_rn(a, __fmul_rn(w, v)); }
+__device__ __forceinline__ void vmad(float2& a, float w, const float2& v) {
+    a.x = __fadd_rn(a.x, __fmul_rn(w, v.x)); a.y = __fadd_rn(a.y, __fmul_rn(w, v.y));
+}
+__device__ __forceinline__ void vmad(float4& a, float w, const float4& v) {
+    a.x = __fadd_rn(a.x, __fmul_rn(w, v.x)); a.y = __fadd_rn(a.y, __fmul_rn(w, v.y));
+    a.z = __fadd_rn(a.z, __fmul_rn(w, v.z)); a.w = __fadd_rn(a.w, __fmul_rn(w, v.w));
+}
+__device__ __forceinline__ void vdiv(float& a, float d) { a = a / d; }
+__device__ __forceinline__ void vdiv(float2& a, float d) { a.x /= d; a.y /= d; }
+__device__ __forceinline__ void vdiv(float4& a, float d) { a.x /= d; a.y /= d; a.z /= d; a.w /= d; }
+__device__ __forceinline__ void vscale(float& a, float s) { a *= s; }
+__device__ __forceinline__ void vscale(float2& a, float s) { a.x *= s; a.y *= s; }
+__device__ __forceinline__ void vscale(float4& a, float s) { a.x *= s; a.y *= s; a.z *= s; a.w *= s; }
+
+struct AggArgs {
+    const int32_t* rowptr;
+    const int32_t* col;
+    const float* x;
+    int64_t ldx;
+    int64_t n_rows;
+    int nchunks;           // ceil(F / VEC)
+    int lshift;            // log2(L)
+    int row_mode;          // 0: none, 1: divide by max(row length, 1), 2: multiply by row_scale[i]
+    const float* row_scale;
+    const float* edge_w;   // per CSR position, nullable
+    const float* nbr_w;    // indexed by col[k], nullable
+    const float* add;      // [n_rows, ldadd], nullable
+    int64_t ldadd;
+    float* out;
+    int64_t ldo;
+};
+
+template <int VEC, bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_aggregate(const AggArgs a) {
+    using V = typename VecT<VEC>::T;
+    const int lane = threadIdx.x & 63;
+    const int L = 1 << a.lshift;
+    const int lr = lane & (L - 1);
+    const int sub = lane >> a.lshift;
+    const int rows_per_wave = 64 >> a.lshift;
+    const int blk = hgv_xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t wave = (int64_t)blk * 4 + (threadIdx.x >> 6);
+    const int64_t row = wave * rows_per_wave + sub;
+    if (row >= a.n_rows) return;
+    const int start = a.rowptr[row], end = a.rowptr[row + 1];
+
+    // Every lane of the group walks the segment (it is the shuffle source for its slot of
+    // column indices); lanes past the last chunk shadow the last chunk and store nothing.
+    for (int c0 = 0; c0 < a.nchunks; c0 += L) {
+        const bool owns = c0 + lr < a.nchunks;
+        const int c = owns ? c0 + lr : a.nchunks - 1;
+        V acc;
+        vzero<VEC>(acc);
+        const float* xc = a.x + (int64_t)c * VEC;
+        for (int base = start; base < end; base += L) {
+            const int k = base + lr;
+            int my_col = 0;
+            float my_w = 1.f;
+            if (k < end) {
+                my_col = a.col[k];
+                if (WEIGHTED) {
+                    if (a.edge_w) my_w = a.edge_w[k];
+                    if (a.nbr_w) my_w *= a.nbr_w[my_col];
+                }
+            }
+            const int cnt = min(L, end - base);
+            int j = 0;
+            // four independent row loads in flight per lane; adds stay in segment order
+            for (; j + 4 <= cnt; j += 4) {
+                const int c0_ = __shfl(my_col, j, L), c1_ = __shfl(my_col, j + 1, L);
+                const int c2_ = __shfl(my_col, j + 2, L), c3_ = __shfl(my_col, j + 3, L);
+                const V v0 = *reinterpret_cast<const V*>(xc + (int64_t)c0_ * a.ldx);
+                const V v1 = *reinterpret_cast<const V*>(xc + (int64_t)c1_ * a.ldx);
+                const V v2 = *reinterpret_cast<const V*>(xc + (int64_t)c2_ * a.ldx);
+                const V v3 = *reinterpret_cast<const V*>(xc + (int64_t)c3_ * a.ldx);
+                if (WEIGHTED) {
+                    const float w0 = __shfl(my_w, j, L), w1 = __shfl(my_w, j + 1, L);
+                    const float w2 = __shfl(my_w, j + 2, L), w3 = __shfl(my_w, j + 3, L);
+                    vmad(acc, w0, v0); vmad(acc, w1, v1); vmad(acc, w2, v2); vmad(acc, w3, v3);
+                } else {
+                    vadd(acc, v0); vadd(acc, v1); vadd(acc, v2); vadd(acc, v3);
+                }
+            }
+            for (; j < cnt; ++j) {
+                const int cj = __shfl(my_col, j, L);
+                const V v = *reinterpret_cast<const V*>(xc + (int64_t)cj * a.ldx);
+                if (WEIGHTED) {
+                    const float wj = __shfl(my_w, j, L);
+                    vmad(acc, wj, v);
+                } else {
+                    vadd(acc, v);
+                }
+            }
+        }
+        if (a.row_mode == 1) {
+            const int d = end - start;
+            vdiv(acc, (float)(d > 1 ? d : 1));
+        } else if (a.row_mode == 2) {
+            vscale(acc, a.row_scale[row]);
+        }
+        if (owns) {
+            if (a.add) vadd(acc, *reinterpret_cast<const V*>(a.add + row * a.ldadd + (int64_t)c * VEC));
+            *reinterpret_cast<V*>(a.out + row * a.ldo + (int64_t)c * VEC) = acc;
+        }
+    }
+}
+
+bool vec_ok(int vec, int F, const float* p, int64_t ld) {
+    if (p == nullptr) return true;
+    const int64_t need = hgv_cdiv(F, vec) * vec;
+    return hgv_aligned(p, 4 * vec) && (ld % vec == 0) && ld >= need;
+}
+
+int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
+    int vec = 4;
+    while (vec > 1 && !(vec_ok(vec, F, a.x, a.ldx) && vec_ok(vec, F, a.out, a.ldo) && vec_ok(vec, F, a.add, a.ldadd)))
+        vec >>= 1;
+    a.nchunks = (int)hgv_cdiv(F, vec);
+    int ls = 0;
+    while ((1 << ls) < a.nchunks && ls < 6) ++ls;
+    a.lshift = ls;
+    const int rows_per_block = 4 * (64 >> ls);
+    const int64_t nblocks = hgv_cdiv(a.n_rows, rows_per_block);
+    if (nblocks == 0) return HGV_OK;
+    HGV_REQUIRE(nblocks < ((int64_t)1 << 31), HGV_EUNSUPPORTED, "aggregate: too many rows");
+    dim3 g((unsigned)nblocks), b(256);
+#define HGV_AGG_LAUNCH(V)                                                                          \
+    if (weighted) hipLaunchKernelGGL((k_aggregate<V, true>), g, b, 0, st, a);                      \
+    else hipLaunchKernelGGL((k_aggregate<V, false>), g, b, 0, st, a);
+    if (vec == 4) { HGV_AGG_LAUNCH(4) } else if (vec == 2) { HGV_AGG_LAUNCH(2) } else { HGV_AGG_LAUNCH(1) }
+#undef HGV_AGG_LAUNCH
+    HGV_CHECK_LAUNCH("aggregate");
+    return HGV_OK;
+}
+
+}  // namespace
+
+// General entry point.  row_mode: 0 = plain sum, 1 = mean over the row (divide by
+// max(row length, 1)), 2 = multiply by row_scale[i].
+extern "C" int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx,
+                           int F, int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w,
+                           const float* add, int64_t ldadd, float* out, int64_t ldo, hipStream_t stream) {
+    HGV_REQUIRE(n_rows >= 0 && F >= 0, HGV_EINVAL, "agg_fwd: negative size");
+    if (n_rows == 0 || F == 0) return HGV_OK;
+    HGV_REQUIRE(rowptr && col && x && out, HGV_EINVAL, "agg_fwd: null buffer");
+    HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd: leading dimension < F");
+    HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd: bad row_mode");
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo};
+    return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream);
+}
+
+// Backward of the mean/sum aggregation with respect to x: run over the transposed CSR
+// (rows = source nodes, col_t = destination of each out-edge):
+//   gx[j,:] = sum_{k in rowT j} inv_deg[col_t[k]] * g[col_t[k],:]  (+ add[j,:])
+// inv_deg = 1/max(in-degree, 1) for mean aggregation, null for sum aggregation.
+extern "C" int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, const float* g,
+                           int64_t ldg, int F, const float* inv_deg, const float* edge_w_t, const float* add,
+                           int64_t ldadd, float* gx, int64_t ldgx, hipStream_t stream) {
+    return hgv_agg_fwd(rowptr_t, col_t, n_rows, g, ldg, F, 0, nullptr, edge_w_t, inv_deg, add, ldadd, gx, ldgx,
+                       stream);
+}

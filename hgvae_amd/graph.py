@@ -1,0 +1,186 @@
+"""Device-resident graph structure (CSR by target, CSR by source) built once per batch.
+
+PyG operators take a COO ``edge_index`` on every call (reference call sites
+gvae/gvae_skipcon.py:105-118).  Here the first operator that sees an
+``edge_index`` tensor builds a :class:`Graph` with the radix-sort kernel and every
+later layer, both encode passes and the backward pass reuse it.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+def pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def new_padded(rows: int, cols: int, device, zero_pad: bool = True) -> torch.Tensor:
+    """[rows, cols] fp32 view of a buffer whose rows are padded to a multiple of 4 floats."""
+    ld = pad4(cols)
+    buf = torch.empty(rows, ld, dtype=torch.float32, device=device)
+    if zero_pad and ld != cols:
+        buf[:, cols:].zero_()
+    return buf[:, :cols]
+
+
+def ld_of(t: torch.Tensor) -> int:
+    """Leading dimension (elements per row) of a 2-D tensor whose rows are unit-stride."""
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise _lib.HgvError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    if t.size(0) > 1:
+        return t.stride(0)
+    return max(t.stride(0), t.size(1))
+
+
+def rowmajor(t: torch.Tensor) -> torch.Tensor:
+    """Return t if its rows are unit-stride with ld >= cols, else a padded copy."""
+    if t.dim() == 2 and t.dtype == torch.float32 and (t.size(1) <= 1 or t.stride(1) == 1) \
+            and (t.size(0) <= 1 or t.stride(0) >= t.size(1)):
+        return t
+    out = new_padded(t.size(0), t.size(1), t.device)
+    out.copy_(t)
+    return out
+
+
+def is_vec4(t: torch.Tensor) -> bool:
+    return t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 and ld_of(t) >= pad4(t.size(1))
+
+
+def as_padded(t: torch.Tensor) -> torch.Tensor:
+    """Row-major fp32 tensor laid out for the 16-byte kernel paths (copy only if needed)."""
+    t = rowmajor(t)
+    if is_vec4(t):
+        return t
+    out = new_padded(t.size(0), t.size(1), t.device)
+    out.copy_(t)
+    return out
+
+
+class _Csr:
+    __slots__ = ("rowptr", "col", "perm")
+
+    def __init__(self, rowptr, col, perm):
+        self.rowptr, self.col, self.perm = rowptr, col, perm
+
+
+def _build_csr(edge_index: torch.Tensor, n: int, by_src: bool, status: torch.Tensor) -> _Csr:
+    e = edge_index.size(1)
+    dev = edge_index.device
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(e, dtype=torch.int32, device=dev)
+    perm = torch.empty(e, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    ws_bytes = lib.hgv_csr_build_ws(e, n)
+    ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    _lib.call("hgv_csr_build", edge_index.data_ptr(), edge_index.stride(0), edge_index.stride(1), e, n,
+              1 if by_src else 0, rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), status.data_ptr(),
+              ws.data_ptr(), ws.numel(), _lib.stream())
+    return _Csr(rowptr, col, perm)
+
+
+class Graph:
+    """CSR views of one (batched) graph with ``num_nodes`` nodes.
+
+    ``by_dst``: row i lists the sources of the edges into i, in stable edge order
+    (forward aggregation).  ``by_src``: row j lists the targets of the edges out of
+    j (backward aggregation); built on first use.
+    """
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, hold: bool = True):
+        _lib.require_cuda(edge_index)
+        if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+            raise _lib.HgvError(f"edge_index must be int64 [2, E], got {edge_index.dtype} {tuple(edge_index.shape)}")
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_index.size(1))
+        # graph_of() keys its cache by the caller's tensor and passes hold=False: a strong
+        # reference from the cached Graph would keep that cache entry alive forever.
+        self._ei_ref = weakref.ref(edge_index)
+        self._ei_hold = edge_index if hold else None
+        self.status = torch.zeros(1, dtype=torch.int32, device=edge_index.device)
+        self.by_dst = _build_csr(edge_index, self.num_nodes, False, self.status)
+        self._by_src: Optional[_Csr] = None
+        self._inv_deg = None
+        self._loops: Optional["Graph"] = None
+        self._t2f = None
+
+    @property
+    def edge_index(self) -> torch.Tensor:
+        ei = self._ei_ref()
+        if ei is None:
+            raise _lib.HgvError("the edge_index tensor this Graph was built from no longer exists")
+        return ei
+
+    @property
+    def by_src(self) -> _Csr:
+        if self._by_src is None:
+            self._by_src = _build_csr(self.edge_index, self.num_nodes, True, self.status)
+        return self._by_src
+
+    @property
+    def in_degree(self) -> torch.Tensor:
+        rp = self.by_dst.rowptr
+        return rp[1:] - rp[:-1]
+
+    @property
+    def inv_deg(self) -> torch.Tensor:
+        """1 / max(in-degree, 1) as fp32 [N]."""
+        if self._inv_deg is None:
+            self._inv_deg = self.in_degree.clamp(min=1).to(torch.float32).reciprocal()
+        return self._inv_deg
+
+    @property
+    def src_pos_to_dst_pos(self) -> torch.Tensor:
+        """For each position of the by-source CSR, the position of the same edge in the by-target CSR."""
+        if self._t2f is None:
+            inv = torch.empty(self.num_edges, dtype=torch.int64, device=self.by_dst.perm.device)
+            inv[self.by_dst.perm.long()] = torch.arange(self.num_edges, device=inv.device)
+            self._t2f = inv[self.by_src.perm.long()]
+        return self._t2f
+
+    def with_self_loops(self) -> "Graph":
+        """Graph of (edges minus existing self loops) followed by one loop per node.
+
+        This is the edge list GATConv (remove_self_loops + add_self_loops) and GCNConv
+        (add_remaining_self_loops, unweighted) aggregate over.
+        """
+        if self._loops is None:
+            ei = self.edge_index
+            keep = ei[0] != ei[1]
+            if not bool(keep.all()):
+                ei = ei[:, keep]
+            loop = torch.arange(self.num_nodes, dtype=torch.int64, device=ei.device)
+            self._loops = Graph(torch.cat([ei, loop.unsqueeze(0).expand(2, -1)], dim=1).contiguous(), self.num_nodes,
+                                hold=True)
+        return self._loops
+
+    def check(self) -> None:
+        """Synchronising validity check: raises if an index was outside [0, num_nodes)."""
+        if int(self.status.item()) != 0:
+            raise _lib.HgvError("edge_index holds node indices outside [0, num_nodes)")
+
+
+# edge_index tensor object -> Graph, dropped when the tensor dies
+_cache: "dict[int, tuple]" = {}
+
+
+def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
+    """Graph for an ``edge_index`` tensor (cached per tensor object and version) or pass-through."""
+    if isinstance(edge_index, Graph):
+        return edge_index
+    key = id(edge_index)
+    hit = _cache.get(key)
+    if hit is not None:
+        ref, version, n, g = hit
+        if ref() is edge_index and version == edge_index._version and (num_nodes is None or n == num_nodes):
+            return g
+    if num_nodes is None:
+        raise _lib.HgvError("num_nodes is required to build a Graph")
+    g = Graph(edge_index, num_nodes, hold=False)
+    ref = weakref.ref(edge_index, lambda _r, k=key: _cache.pop(k, None))
+    _cache[key] = (ref, edge_index._version, num_nodes, g)
+    return g

@@ -1,0 +1,193 @@
+"""Graph-VAE models and train/eval loops with the reference's Python interface.
+
+Module trees reproduce the reference's ``state_dict`` keys
+(``encoder1.0.lin_l.weight`` ... ``decoder3.3.bias``, gvae/gvae_skipcon.py:60-101), so
+checkpoints written by either side load in the other.  The ``Dropout`` /
+``BatchNorm1d`` children only hold hyper-parameters, affine weights and running
+statistics: the arithmetic of each level runs in fused HIP kernels
+(aggregation -> projection pair -> relu/dropout/batch-norm).
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import functional as Fn
+from .graph import as_padded, graph_of
+from .nn import SAGEConv
+
+_pad_cache: "dict[int, tuple]" = {}
+
+
+def padded_input(x: torch.Tensor) -> torch.Tensor:
+    """Feature matrix laid out for 16-byte loads; the copy is cached per input tensor object."""
+    if x.requires_grad:
+        return x
+    key = id(x)
+    hit = _pad_cache.get(key)
+    if hit is not None and hit[0]() is x and hit[1] == x._version:
+        return hit[2]
+    p = as_padded(x)
+    if p is not x:
+        _pad_cache[key] = (weakref.ref(x, lambda _r, k=key: _pad_cache.pop(k, None)), x._version, p)
+    return p
+
+
+def split_head(ml: torch.Tensor, z_dim: int):
+    """chunk(2, dim=-1) of the [N, 2Z] head output; the halves remember their parent buffer."""
+    mean, log_std = ml[:, :z_dim], ml[:, z_dim:]
+    mean._hgv_parent = ml
+    log_std._hgv_parent = ml
+    return mean, log_std
+
+
+def join_head(mean: torch.Tensor, log_std: torch.Tensor) -> torch.Tensor:
+    """Inverse of :func:`split_head`; falls back to a concatenation for unrelated tensors."""
+    parent = getattr(mean, "_hgv_parent", None)
+    if parent is not None and parent is getattr(log_std, "_hgv_parent", None) \
+            and parent.size(1) == mean.size(1) + log_std.size(1):
+        return parent
+    return torch.cat([mean, log_std], dim=1)
+
+
+def compute_rmsd(coords1: torch.Tensor, coords2: torch.Tensor) -> torch.Tensor:
+    """Mean over rows of sqrt(mean over columns of squared difference) (gvae_skipcon.py:207-215)."""
+    assert coords1.size() == coords2.size(), "Coordinate tensors must have the same shape"
+    return torch.sqrt(((coords1 - coords2) ** 2).mean(dim=-1)).mean()
+
+
+class _VAEBase(nn.Module):
+    dropout_prob: float
+    n_samples: int
+
+    # one encoder/decoder level: conv-or-linear output -> (relu) -> dropout -> batch norm
+    def _finish(self, y, dropout: Optional[nn.Dropout], bn: nn.BatchNorm1d, relu: bool):
+        p = dropout.p if dropout is not None else 0.0
+        return Fn.bn_act(y, bn, relu, p, self.training)
+
+    def _sage_level(self, seq, x, g):
+        return self._finish(seq[0](x, g), seq[1], seq[2], relu=True)
+
+    def reparameterize(self, mean, log_std):
+        ml = join_head(mean, log_std)
+        return Fn.reparameterize(ml, mean.size(1), self.n_samples)
+
+    def kl_divergence(self, mean, log_std):
+        return Fn.kl_divergence(join_head(mean, log_std), mean.size(1))
+
+    def _device(self):
+        return next(self.parameters()).device
+
+
+class SkipconVAE(_VAEBase):
+    """gvae/gvae_skipcon.py:53-156: three SAGE levels, mean/log_std head, concat-skip decoder."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, n_samples=10, dropout_prob=0.5):
+        super().__init__()
+        h, z, p = hidden_channels, out_channels, dropout_prob
+        self.dropout_prob, self.n_samples = p, n_samples
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, h, z
+        self.encoder1 = nn.Sequential(SAGEConv(in_channels, h), nn.Dropout(p), nn.BatchNorm1d(h))
+        self.encoder2 = self._make_level2(h, p)
+        self.encoder3 = nn.Sequential(SAGEConv(h, h), nn.Dropout(p), nn.BatchNorm1d(h), SAGEConv(h, 2 * z))
+        self.decoder1 = nn.Sequential(nn.Linear(z, h), nn.Dropout(p), nn.BatchNorm1d(h))
+        self.decoder2 = nn.Sequential(nn.Linear(2 * h, h), nn.Dropout(p), nn.BatchNorm1d(h))
+        self.decoder3 = nn.Sequential(nn.Linear(2 * h, h), nn.Dropout(p), nn.BatchNorm1d(h), nn.Linear(h, in_channels))
+
+    def _make_level2(self, h, p):
+        return nn.Sequential(SAGEConv(h, h), nn.Dropout(p), nn.BatchNorm1d(h))
+
+    def _level2(self, x1, g):
+        return self._sage_level(self.encoder2, x1, g)
+
+    def encode(self, x, edge_index):
+        g = graph_of(edge_index, x.size(0))
+        x = padded_input(x)
+        x1 = self._sage_level(self.encoder1, x, g)
+        x2 = self._level2(x1, g)
+        x3 = self._sage_level(self.encoder3, x2, g)
+        mean, log_std = split_head(self.encoder3[3](x3, g), self.out_channels)
+        return x1, x2, mean, log_std
+
+    def decode(self, z, skip1, skip2):
+        h = self.hidden_channels
+        d1, d2, d3 = self.decoder1, self.decoder2, self.decoder3
+        h1 = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=False)
+        w2 = d2[0].weight
+        h2 = self._finish(Fn.dual_linear(h1, w2[:, :h], skip1, w2[:, h:], d2[0].bias), d2[1], d2[2], relu=False)
+        w3 = d3[0].weight
+        h3 = self._finish(Fn.dual_linear(h2, w3[:, :h], skip2, w3[:, h:], d3[0].bias), d3[1], d3[2], relu=False)
+        return Fn.dual_linear(h3, d3[3].weight, None, None, d3[3].bias)
+
+    def forward(self, x, edge_index, batch=None):
+        skip1, skip2, mean, log_std = self.encode(x, edge_index)
+        z = self.reparameterize(mean, log_std)
+        return self.decode(z, skip1, skip2), mean, log_std
+
+    def recon_loss(self, x, reconstruction):
+        return Fn.mse_loss(reconstruction, padded_input(x))
+
+
+def _to_device(data, device):
+    for name in ("x", "edge_index", "batch", "edge_attr"):
+        t = getattr(data, name, None)
+        if isinstance(t, torch.Tensor) and t.device != device:
+            setattr(data, name, t.to(device))
+    return data
+
+
+def train_vae(model, loader, optimizer, lambda_kl=1.0):
+    """One epoch; per batch: forward, SECOND encode, mse + lambda*kl, backward, step
+    (gvae/gvae_skipcon.py:159-187).  The running loss stays on the device; one host sync per epoch."""
+    model.train()
+    dev = model._device()
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    for data in loader:
+        data = _to_device(data, dev)
+        optimizer.zero_grad()
+        loss = train_step_loss(model, data.x, data.edge_index, data.batch, lambda_kl)
+        loss.backward()
+        optimizer.step()
+        total += loss.detach()
+    return float(total.item()) / len(loader)
+
+
+def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
+    """Loss of one reference train step (no backward)."""
+    out = model(x, edge_index, batch)
+    enc = model.encode(x, edge_index)
+    mean, log_std = enc[-2], enc[-1]
+    recon_loss = Fn.mse_loss(out[0], padded_input(x))
+    kl_loss = model.kl_divergence(mean, log_std)
+    return recon_loss + lambda_kl * kl_loss
+
+
+def validate_vae(model, loader):
+    """gvae/gvae_skipcon.py:190-204: eval mode, same double pass, recon + kl."""
+    model.eval()
+    dev = model._device()
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        for data in loader:
+            data = _to_device(data, dev)
+            total += train_step_loss(model, data.x, data.edge_index, data.batch, 1.0)
+    return float(total.item()) / len(loader)
+
+
+def test_vae_rmsd(model, loader):
+    """gvae/gvae_skipcon.py:218-233: RMSD between the first three columns of input and reconstruction."""
+    model.eval()
+    dev = model._device()
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    with torch.no_grad():
+        for data in loader:
+            data = _to_device(data, dev)
+            recon = model(data.x, data.edge_index, data.batch)[0]
+            total += compute_rmsd(data.x[:, :3], recon[:, :3])
+    return float(total.item()) / len(loader)
+
+
+test_vae_rmsd.__test__ = False  # not a pytest test

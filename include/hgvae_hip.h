@@ -1,0 +1,118 @@
+/* libhgvae_hip.so - C ABI of the MI355X (gfx950) graph-VAE message-passing kernels.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer owned by the caller (inputs, outputs, workspaces);
+ *    the library never allocates, frees or synchronises.  Every call is asynchronous on
+ *    the caller's stream.
+ *  - Return value: 0 on success, negative on error (HGV_E*); hgv_last_error() returns the
+ *    message of the last failing call made by the calling host thread.
+ *  - Matrices are row-major fp32 with an explicit leading dimension (elements per row).
+ *    16-byte vector paths are used when base pointers are 16-byte aligned and leading
+ *    dimensions are multiples of 4 and cover ceil(F/4)*4 columns (pad columns are then read
+ *    and written); otherwise scalar paths run.
+ *  - Index arrays inside the library are int32; edge_index at the boundary is int64 as in
+ *    PyTorch Geometric.
+ *
+ * Each entry point cites the reference interface (file:line under the reference tree) whose
+ * CPU operator sequence it replaces.  The reference delegates these to PyTorch Geometric
+ * (SAGEConv, GATConv, SAGPooling, GCNConv, Batch) and torch.nn.
+ */
+#ifndef HGVAE_HIP_H
+#define HGVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hgv_stream_t; /* == hipStream_t */
+
+#define HGV_OK 0
+#define HGV_EINVAL (-1)
+#define HGV_EUNSUPPORTED (-2)
+#define HGV_ELAUNCH (-3)
+#define HGV_EWORKSPACE (-4)
+
+int hgv_version(void);
+const char* hgv_last_error(void);
+
+/* ---- CSR construction (no reference counterpart: PyG consumes COO edge_index directly at
+ *      gvae/gvae_skipcon.py:105-118; built once per batch and shared by every layer) -------
+ * key row = edge_index[1] (targets) when by_src == 0, edge_index[0] (sources) otherwise.
+ *   perm   = stable argsort of the key row                      [E]
+ *   col    = the other row, permuted                            [E]
+ *   rowptr = [0, cumsum(bincount(key, N))]                      [N+1]
+ * edge_index element (r, e) is read at edge_index[r*ld_row + e*ld_col] (any strides).
+ * status (nullable, caller-zeroed int32): set to 1 if an index was outside [0, N) (such
+ * indices are clamped so no kernel reads out of bounds). */
+size_t hgv_csr_build_ws(int64_t E, int64_t N);
+int hgv_csr_build(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int64_t E, int64_t N, int by_src,
+                  int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
+                  hgv_stream_t stream);
+
+/* Stable LSD radix sort of (uint32 key, int32 value) pairs on key bits [bit_lo, bit_hi).
+ * vals_in may be null (values = positions).  Used by the per-graph top-k of SAGPooling
+ * (autoencoder/vae_with_pool.py:39). */
+size_t hgv_sort_pairs_ws(int64_t n);
+int hgv_sort_pairs_u32(const uint32_t* keys_in, const int32_t* vals_in, int64_t n, int bit_lo, int bit_hi,
+                       uint32_t* keys_out, int32_t* vals_out, void* ws, size_t ws_bytes, hgv_stream_t stream);
+
+/* ---- neighbour aggregation: SAGEConv mean aggregation gvae/gvae_skipcon.py:105,110,115,118;
+ *      GraphConv sum autoencoder/vae_with_pool.py:39; GATConv weighted sum
+ *      gvae/gvae_skipcon_attention.py:109 --------------------------------------------------
+ *   out[i,:] = rs_i * sum_{k in [rowptr[i], rowptr[i+1])} w_k * x[col[k], :]  (+ add[i,:])
+ *   rs_i: row_mode 0 -> 1; 1 -> 1/max(row length, 1) (true division); 2 -> row_scale[i]
+ *   w_k = edge_w[k] (nullable) * nbr_w[col[k]] (nullable)
+ * Rows are summed in CSR order; the unweighted result is bit-identical to a sequential
+ * scatter_add_ in stable edge order. */
+int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx, int F,
+                int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w, const float* add,
+                int64_t ldadd, float* out, int64_t ldo, hgv_stream_t stream);
+/* Backward w.r.t. x (autograd of the above, loss.backward() gvae/gvae_skipcon.py:183): the same
+ * reduction over the TRANSPOSED CSR, inv_deg = 1/max(in-degree,1) per target (null for sums). */
+int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, const float* g, int64_t ldg, int F,
+                const float* inv_deg, const float* edge_w_t, const float* add, int64_t ldadd, float* gx,
+                int64_t ldgx, hgv_stream_t stream);
+
+/* ---- fused (ReLU) -> Dropout -> BatchNorm1d over nodes: gvae/gvae_skipcon.py:105-107,
+ *      110-112,115-117,124,130,136 ----------------------------------------------------------
+ * y is the pre-activation [N, H].  Dropout keep mask: explicit uint8 [N,H] (contiguous), or
+ * Philox4x32-10 keyed by (seed, offset) when mask is null and p > 0.  Biased batch variance
+ * for normalisation, unbiased for the running update (torch.nn.BatchNorm1d semantics). */
+size_t hgv_bn_act_ws(int64_t N, int H);
+int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
+                   uint64_t seed, uint64_t offset, const float* gamma, const float* beta, float eps,
+                   float* running_mean, float* running_var, float momentum, float* save_mean, float* save_rstd,
+                   float* out, int64_t ldo, void* ws, size_t ws_bytes, hgv_stream_t stream);
+int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, int relu, const float* gamma, const float* beta,
+                    float eps, const float* running_mean, const float* running_var, float* out, int64_t ldo,
+                    hgv_stream_t stream);
+int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
+                   const uint8_t* mask, uint64_t seed, uint64_t offset, const float* gamma, const float* save_mean,
+                   const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* ws,
+                   size_t ws_bytes, hgv_stream_t stream);
+
+/* ---- reparameterisation / KL / MSE: gvae/gvae_skipcon.py:138-142, :153-156, :174 ----------
+ * ml = [mean | log_std], [N, 2Z] with leading dimension ldm.
+ * eps: explicit [n_samples, N, Z] draws or null (Philox + Box-Muller from seed/offset).
+ * eps_bar [N, Z] (mean of the draws) is an output kept for the backward pass. */
+size_t hgv_loss_ws(void);
+int hgv_reparam_fwd(const float* ml, int64_t ldm, int64_t N, int Z, int n_samples, const float* eps, uint64_t seed,
+                    uint64_t offset, float* z, int64_t ldz, float* eps_bar, hgv_stream_t stream);
+int hgv_reparam_bwd(const float* gz, int64_t ldgz, const float* ml, int64_t ldm, int64_t N, int Z,
+                    const float* eps_bar, float* gml, int64_t ldg, hgv_stream_t stream);
+int hgv_kl_fwd(const float* ml, int64_t ldm, int64_t N, int Z, float* out, void* ws, size_t ws_bytes,
+               hgv_stream_t stream);
+int hgv_kl_bwd(const float* ml, int64_t ldm, int64_t N, int Z, const float* gout, float* gml, int64_t ldg,
+               int accumulate, hgv_stream_t stream);
+int hgv_mse_fwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, float* out, void* ws,
+                size_t ws_bytes, hgv_stream_t stream);
+int hgv_mse_bwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, const float* gout,
+                float* gr, int64_t ldg, hgv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGVAE_HIP_H */

@@ -1,0 +1,261 @@
+"""Kernel-level parity: HIP path (through the C ABI) vs the CPU oracle, same seeded inputs.
+
+Integer/index results are compared bit-exactly; the unweighted aggregation forward is also
+bit-exact (same summation order as scatter_add_); other fp32 results use the norm-wise
+tolerance  max|a-b| <= rtol * max|b| + atol  with rtol 1e-5 forward / 1e-4 gradients.
+"""
+import pytest
+import torch
+
+from graphs import local_graph, path_batch, random_graph
+from oracle import pyg_ops as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_RTOL, BWD_RTOL, ATOL = 1e-5, 1e-4, 1e-6
+
+
+def close(a, b, rtol, atol=ATOL):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= rtol * ref + atol, f"max err {err:.3e} vs ref scale {ref:.3e} (rtol {rtol})"
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ CSR build
+CSR_CASES = {
+    "path_batch": lambda: path_batch([5, 1, 138, 454, 2]),
+    "random_small": lambda: random_graph(37, 200, seed=1),
+    "random_two_pass": lambda: random_graph(5000, 60000, seed=2),
+    "random_three_pass": lambda: random_graph(70000, 300000, seed=3),
+    "local_100k": lambda: local_graph(100000, 20, seed=4),
+    "single_node_loops": lambda: (torch.zeros(2, 7, dtype=torch.long), 1, torch.zeros(1, dtype=torch.long)),
+    "tile_boundary": lambda: random_graph(300, 4096 * 3, seed=5),
+    "tile_boundary_plus1": lambda: random_graph(300, 4096 * 3 + 1, seed=6),
+}
+
+
+@pytest.mark.parametrize("name", list(CSR_CASES))
+@pytest.mark.parametrize("by_src", [False, True])
+def test_csr_build_bit_exact(name, by_src):
+    from hgvae_amd.graph import Graph
+    ei, n, _ = CSR_CASES[name]()
+    g = Graph(ei.to(dev()), n)
+    csr = g.by_src if by_src else g.by_dst
+    rp, col, perm = O.csr_reference(ei, n, by_src)
+    g.check()
+    assert torch.equal(csr.rowptr.cpu(), rp)
+    assert torch.equal(csr.perm.cpu(), perm)
+    assert torch.equal(csr.col.cpu(), col)
+
+
+def test_csr_build_strided_edge_index_and_empty():
+    from hgvae_amd.graph import Graph
+    ei_t = torch.randint(0, 50, (333, 2), generator=torch.Generator().manual_seed(7))
+    ei = ei_t.to(dev()).t()  # [2, E] with strides (1, 2): the layout of the bundled graphs
+    assert ei.stride() == (1, 2)
+    g = Graph(ei, 50)
+    rp, col, perm = O.csr_reference(ei_t.t().contiguous(), 50)
+    assert torch.equal(g.by_dst.rowptr.cpu(), rp) and torch.equal(g.by_dst.col.cpu(), col)
+    g0 = Graph(torch.zeros(2, 0, dtype=torch.long, device=dev()), 9)
+    assert torch.equal(g0.by_dst.rowptr.cpu(), torch.zeros(10, dtype=torch.int32))
+
+
+def test_csr_build_flags_out_of_range():
+    from hgvae_amd import _lib
+    from hgvae_amd.graph import Graph
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev())
+    g = Graph(ei, 3)
+    with pytest.raises(_lib.HgvError):
+        g.check()
+
+
+def test_sort_pairs_matches_stable_sort():
+    from hgvae_amd import _lib
+    gen = torch.Generator().manual_seed(11)
+    for n, lo, hi in [(1, 0, 32), (1000, 0, 32), (50000, 0, 32), (9000, 8, 24), (4097, 0, 8)]:
+        k32 = torch.randint(0, 2**32, (n,), generator=gen, dtype=torch.int64)
+        kbits = torch.where(k32 >= 2**31, k32 - 2**32, k32).to(torch.int32).to(dev())  # uint32 bit pattern
+        ko = torch.empty_like(kbits)
+        vo = torch.empty(n, dtype=torch.int32, device=dev())
+        lib = _lib.load()
+        ws = torch.empty(lib.hgv_sort_pairs_ws(n), dtype=torch.uint8, device=dev())
+        _lib.call("hgv_sort_pairs_u32", kbits.data_ptr(), None, n, lo, hi, ko.data_ptr(), vo.data_ptr(),
+                  ws.data_ptr(), ws.numel(), _lib.stream())
+        field = (k32 >> lo) & ((1 << (hi - lo)) - 1)
+        ref = torch.sort(field, stable=True).indices.to(torch.int32)
+        assert torch.equal(vo.cpu(), ref), (n, lo, hi)
+
+
+# ------------------------------------------------------------------ aggregation
+@pytest.mark.parametrize("F", [1, 6, 28, 56, 105, 128, 138, 256, 276])
+@pytest.mark.parametrize("mean", [True, False])
+def test_aggregate_forward_bit_exact(F, mean):
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    ei, n, _ = random_graph(700, 9000, seed=F)
+    x = torch.randn(n, F, generator=torch.Generator().manual_seed(F))
+    ref = (O.scatter_mean if mean else O.scatter_sum)(x.index_select(0, ei[0]), ei[1], n)
+    g = Graph(ei.to(dev()), n)
+    out = Fn.aggregate(x.to(dev()), g, mean=mean)
+    assert out.shape == ref.shape
+    assert torch.equal(out.cpu(), ref), (out.cpu() - ref).abs().max()
+
+
+def test_aggregate_known_answer_path():
+    """3-node path 0->1->2: mean aggregation is [0, x0, x1] (node 0 has no in-edge)."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    ei = torch.tensor([[0, 1], [1, 2]])
+    x = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+    out = Fn.aggregate(x.to(dev()), Graph(ei.to(dev()), 3), mean=True).cpu()
+    assert torch.equal(out, torch.tensor([[0.0, 0.0], [1.0, 2.0], [3.0, 4.0]]))
+
+
+@pytest.mark.parametrize("F", [6, 56, 138])
+@pytest.mark.parametrize("mean", [True, False])
+def test_aggregate_backward(F, mean):
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    ei, n, _ = random_graph(500, 6000, seed=100 + F)
+    gen = torch.Generator().manual_seed(F)
+    x = torch.randn(n, F, generator=gen, requires_grad=True)
+    gout = torch.randn(n, F, generator=gen)
+    ref = (O.scatter_mean if mean else O.scatter_sum)(x.index_select(0, ei[0]), ei[1], n)
+    ref.backward(gout)
+    xd = x.detach().to(dev()).requires_grad_(True)
+    out = Fn.aggregate(xd, Graph(ei.to(dev()), n), mean=mean)
+    out.backward(gout.to(dev()))
+    close(xd.grad, x.grad, BWD_RTOL)
+
+
+def test_aggregate_large_local_graph_vs_oracle():
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    ei, n, _ = local_graph(20000, 20, seed=9)
+    x = torch.randn(n, 128, generator=torch.Generator().manual_seed(1))
+    ref = O.scatter_mean(x.index_select(0, ei[0]), ei[1], n)
+    out = Fn.aggregate(x.to(dev()), Graph(ei.to(dev()), n), mean=True)
+    assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------ relu/dropout/batch-norm
+@pytest.mark.parametrize("H", [6, 138, 256, 276])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.49])
+def test_bn_act_forward_backward(H, relu, p):
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import NoiseTape, use_noise
+    gen = torch.Generator().manual_seed(H + int(p * 100))
+    n = 1237
+    y = (torch.randn(n, H, generator=gen) * 1.7 + 0.3).requires_grad_(True)
+    mask = torch.bernoulli(torch.full((n, H), 1 - p), generator=gen)
+    gout = torch.randn(n, H, generator=gen)
+    bn = torch.nn.BatchNorm1d(H)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(H, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(H, generator=gen))
+    bn_d = torch.nn.BatchNorm1d(H)
+    bn_d.load_state_dict(bn.state_dict())
+    bn_d = bn_d.to(dev())
+    # oracle: torch modules with the explicit mask
+    t = torch.relu(y) if relu else y
+    t = O.dropout_with(t, p, True, O.NoiseTape([mask]))
+    ref = bn(t)
+    ref.backward(gout)
+    yd = y.detach().to(dev()).requires_grad_(True)
+    with use_noise(NoiseTape([mask])):
+        out = Fn.bn_act(yd, bn_d, relu, p, training=True)
+    out.backward(gout.to(dev()))
+    close(out, ref, FWD_RTOL)
+    close(yd.grad, y.grad, BWD_RTOL)
+    close(bn_d.weight.grad, bn.weight.grad, BWD_RTOL)
+    close(bn_d.bias.grad, bn.bias.grad, BWD_RTOL)
+    close(bn_d.running_mean, bn.running_mean, FWD_RTOL)
+    close(bn_d.running_var, bn.running_var, FWD_RTOL)
+    assert int(bn_d.num_batches_tracked) == 1
+    # eval mode uses the running statistics
+    bn.eval()
+    ref_e = bn(torch.relu(y) if relu else y)
+    out_e = Fn.bn_act(yd.detach(), bn_d, relu, p, training=False)
+    close(out_e, ref_e, FWD_RTOL)
+
+
+def test_bn_act_large_mean_is_stable():
+    """Columns with mean >> std: shifted sums must not lose the variance."""
+    from hgvae_amd import functional as Fn
+    gen = torch.Generator().manual_seed(3)
+    y = torch.randn(5000, 8, generator=gen) * 0.01 + 100.0
+    bn = torch.nn.BatchNorm1d(8)
+    ref = bn(y)
+    out = Fn.bn_act(y.to(dev()), torch.nn.BatchNorm1d(8).to(dev()), False, 0.0, training=True)
+    close(out, ref, 1e-3)
+
+
+def test_bn_act_philox_dropout_statistics_and_determinism():
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    y = torch.ones(4096, 64, device=dev())
+    bn = torch.nn.BatchNorm1d(64, affine=False).to(dev())
+    outs = []
+    for _ in range(2):
+        with use_noise(PhiloxNoise(seed=123)):
+            outs.append(Fn.bn_act(y, bn, False, 0.5, training=True))
+    assert torch.equal(outs[0], outs[1])
+    # after batch norm a Bernoulli(0.5)*2 column is +-1: check keep fraction ~ 0.5
+    keep = (outs[0] > 0).float().mean().item()
+    assert abs(keep - 0.5) < 0.01
+
+
+# ------------------------------------------------------------------ reparam / KL / MSE
+def test_reparam_kl_mse_forward_backward():
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from oracle.models import kl_divergence, reparameterize
+    gen = torch.Generator().manual_seed(5)
+    n, z, f, ns = 777, 28, 60, 10
+    ml = (torch.randn(n, 2 * z, generator=gen) * 0.5).requires_grad_(True)
+    eps = torch.randn(ns, n, z, generator=gen)
+    x = torch.randn(n, f, generator=gen)
+    w = torch.randn(z, f, generator=gen)
+    mean, log_std = ml.chunk(2, dim=-1)
+    zz = reparameterize(mean, log_std, ns, O.NoiseTape([eps]))
+    rec = zz @ w
+    loss_ref = torch.nn.functional.mse_loss(rec, x) + 0.7 * kl_divergence(mean, log_std)
+    loss_ref.backward()
+
+    mld = ml.detach().to(dev()).requires_grad_(True)
+    with use_noise(NoiseTape([eps])):
+        zd = Fn.reparameterize(mld, z, ns)
+    recd = zd @ w.to(dev())
+    loss = Fn.mse_loss(recd, x.to(dev())) + 0.7 * Fn.kl_divergence(mld, z)
+    loss.backward()
+    close(zd, zz, FWD_RTOL)
+    close(loss, loss_ref, FWD_RTOL)
+    close(mld.grad, ml.grad, BWD_RTOL)
+
+
+def test_kl_known_answers():
+    from hgvae_amd import functional as Fn
+    ml = torch.zeros(10, 8, device=dev())
+    assert Fn.kl_divergence(ml, 4).item() == 0.0  # mu = 0, log_std = 0
+    ml[:, :4] = 1.0
+    assert abs(Fn.kl_divergence(ml, 4).item() - 2.0) < 1e-6  # 0.5 * sum mu^2 = 2
+
+
+def test_reparam_philox_moments():
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    ml = torch.zeros(20000, 56, device=dev())
+    with use_noise(PhiloxNoise(seed=9)):
+        z = Fn.reparameterize(ml, 28, 10)
+    # mean of 10 standard normals: mean 0, std 1/sqrt(10)
+    assert abs(z.mean().item()) < 5e-3
+    assert abs(z.std().item() - 10 ** -0.5) < 5e-3
