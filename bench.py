@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""GVAE train-step benchmark (graphs/s, edge-messages/s, aggregation HBM roofline).
+
+  python bench.py --gpus N --steps K --warmup W [--workload protein256|large|chig32]
+
+One "step" is the reference's train_vae body for one mini-batch (gvae/gvae_skipcon.py:163-185):
+forward, second encode, mse + kl, backward, gradient all-reduce (N > 1), Adam step.
+Default workload: BASELINE config "synthetic protein-like graphs (~5k nodes, ~60k edges each),
+batch 256 over 8 GPUs" - each rank holds its 32-graph shard (weak scaling), model
+VAE(105, 138, 28) of gvae_skipcon.  Inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line.  The CPU baseline (the oracle = reference-equivalent PyG operator
+sequence restated in torch, timed on this host's cores) runs on rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def agg_bytes(n, f, e):
+    """Algorithmic bytes of one aggregation launch: one neighbour row per message, the output, col, rowptr."""
+    return 4 * f * e + 4 * f * n + 4 * e + 4 * (n + 1)
+
+
+def build_workload(name, rank, device):
+    from hgvae_amd import synthetic
+    if name == "protein256":
+        batch = synthetic.protein_like_batch(32, seed=1000 + rank, device=device)
+        dims = (105, 138, 28)
+    elif name == "large":
+        batch = synthetic.local_random_graph(100_000, 20, 128, seed=1000 + rank, device=device)
+        dims = (128, 128, 28)
+    elif name == "chig32":
+        batch = synthetic.path_graph_batch([138] * 32, 60, seed=1000 + rank, device=device)
+        dims = (60, 138, 28)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return batch, dims
+
+
+def cpu_baseline(batch, dims, sample_graphs, lambda_kl=1.0):
+    """Time the oracle's train step (forward, second encode, loss, backward, Adam) on host cores."""
+    from hgvae_amd.data import Batch, Data
+    from oracle import models as OM
+    ptr = batch.ptr.cpu().tolist()
+    x, ei = batch.x.cpu(), batch.edge_index.cpu()
+    src_graph = torch.bucketize(ei[0], torch.tensor(ptr[1:]), right=True)
+    items = []
+    for g in range(min(sample_graphs, len(ptr) - 1)):
+        m = src_graph == g
+        items.append(Data(x=x[ptr[g]:ptr[g + 1]], edge_index=ei[:, m] - ptr[g]))
+    sub = Batch.from_data_list(items)
+    threads = torch.get_num_threads()
+    torch.manual_seed(0)
+    model = OM.SkipconVAE(*dims)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model.train()
+
+    def step():
+        opt.zero_grad()
+        loss = OM.skipcon_loss(model, sub.x, sub.edge_index, sub.batch, lambda_kl)[0]
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 10:
+            break
+    return {"value": len(items) * n / dt, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "sample": f"{len(items)} of the {len(ptr) - 1} graphs of rank 0's batch "
+                      f"({sub.x.size(0)} nodes, {sub.edge_index.size(1)} edges), {n} train steps after 1 warm-up, "
+                      f"{dt:.1f} s; torch CPU restatement of the PyG operator sequence",
+            "edge_messages_per_s": 14 * sub.edge_index.size(1) * n / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="protein256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-graphs", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import hgvae_amd
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.distributed import FlatGradBucket, init_from_env
+    from hgvae_amd.graph import graph_of
+    from hgvae_amd.vae import SkipconVAE, train_step_loss
+
+    rank, world, local_rank = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    batch, dims = build_workload(args.workload, rank, device)
+    n_nodes, n_edges, n_graphs = batch.x.size(0), batch.edge_index.size(1), batch.num_graphs
+    torch.manual_seed(0)
+    hgvae_amd.manual_seed(1234 + rank)
+    model = SkipconVAE(*dims).to(device).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    bucket = FlatGradBucket(model.parameters())
+    graph = graph_of(batch.edge_index, n_nodes)  # CSR of the batch: built once, reused by every step
+    graph.check()
+
+    def step():
+        bucket.zero()
+        loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+        loss.backward()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    probe = Fn.LaunchProbe()
+    Fn.set_probe(probe)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    Fn.set_probe(None)
+
+    stats = torch.tensor([elapsed, float(n_graphs), float(n_edges), float(n_nodes)], dtype=torch.float64, device=device)
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        elapsed = mx[0].item()
+    tot_graphs, tot_edges, tot_nodes = stats[1].item(), stats[2].item(), stats[3].item()
+
+    if rank == 0:
+        # roofline of the dominant kernel: unweighted forward aggregation at the hidden width
+        recs = probe.durations_ms()
+        h = dims[1]
+        dom = [ms for (n, f, e, w, ms) in recs if f == h and not w]
+        allb = sum(agg_bytes(n, f, e) + (4 * e if w else 0) for (n, f, e, w, ms) in recs)
+        allms = sum(ms for (*_, ms) in recs)
+        roof = None
+        if dom:
+            avg_ms = sum(dom) / len(dom)
+            achieved = agg_bytes(n_nodes, h, n_edges) / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false> (mean aggregation, F=%d)" % h,
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": len(dom),
+                    "algorithmic_bytes_per_launch": agg_bytes(n_nodes, h, n_edges),
+                    "all_aggregations_GBps": round(allb / (allms * 1e-3) / 1e9, 1) if allms > 0 else None}
+        out = {
+            "metric": "GVAE train graphs/sec", "value": round(tot_graphs * args.steps / elapsed, 2),
+            "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"protein256": "synthetic protein-like graphs (~5k nodes, ~60k directed edges each), "
+                                                  "32 graphs per GPU (global batch 256 at 8 GPUs), gvae_skipcon VAE(105,138,28)",
+                                    "large": "one synthetic graph per GPU: 100k nodes, 2M edges, 128-d features, VAE(128,128,28)",
+                                    "chig32": "32 chignolin-sized path graphs (138 nodes) per GPU, VAE(60,138,28)"}[args.workload],
+                       "graphs_per_gpu": n_graphs, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
+                       "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-3"},
+            "edge_messages_per_s": round(14 * tot_edges * args.steps / elapsed, 1),
+            "loss": round(float(loss.item()), 6),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, dims, args.cpu_sample_graphs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

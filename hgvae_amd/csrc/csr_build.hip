@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void k_scan_partials(int32_t* __restrict__ par
     }
 }
 
-__global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ in, int64_t n,
-                                                    const int32_t* __restrict__ partial,
-                                                    int32_t* __restrict__ out) {
+// in and out may be the same array: a thread reads its 16 inputs before it writes them.
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t* in, int64_t n,
+                                                    const int32_t* __restrict__ partial, int32_t* out) {
     __shared__ int lds[8];
     const int64_t base = (int64_t)blockIdx.x * SC_CHUNK + (int64_t)threadIdx.x * 16;
     int v[16], s = 0;
@@ -326,5 +326,26 @@ extern "C" int hgv_sort_pairs_u32(const uint32_t* keys_in, const int32_t* vals_i
     const int grid = (int)(hgv_cdiv(n, 256) < 4096 ? hgv_cdiv(n, 256) : 4096);
     hipLaunchKernelGGL(k_copy_pairs, dim3(grid), dim3(256), 0, stream, rk, rv, n, keys_out, vals_out);
     HGV_CHECK_LAUNCH("sort_pairs(copy)");
+    return HGV_OK;
+}
+
+// Exclusive prefix sum of an int32 array (in and out may alias).
+extern "C" size_t hgv_exclusive_scan_ws(int64_t n) {
+    if (n < 0) return 0;
+    return hgv_align256((size_t)hgv_cdiv(n > 0 ? n : 1, SC_CHUNK) * 4);
+}
+
+extern "C" int hgv_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+    HGV_REQUIRE(n >= 0, HGV_EINVAL, "exclusive_scan: negative n");
+    if (n == 0) return HGV_OK;
+    HGV_REQUIRE(in && out && ws, HGV_EINVAL, "exclusive_scan: null buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_exclusive_scan_ws(n), HGV_EWORKSPACE, "exclusive_scan: workspace too small");
+    const int np = (int)hgv_cdiv(n, SC_CHUNK);
+    int32_t* partial = (int32_t*)ws;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(np), dim3(256), 0, stream, in, n, partial);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, stream, partial, np);
+    hipLaunchKernelGGL(k_scan_apply, dim3(np), dim3(256), 0, stream, in, n, partial, out);
+    HGV_CHECK_LAUNCH("exclusive_scan");
     return HGV_OK;
 }

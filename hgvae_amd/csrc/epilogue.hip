@@ -138,26 +138,49 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     }
 }
 
-__global__ void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks, int64_t rows_per_block,
-                                    int64_t N, int H, int Hp, float eps, float momentum,
-                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float* __restrict__ save_mean, float* __restrict__ save_rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
+// One workgroup = 16 columns x 16 slices of the partial list; slices are combined through LDS
+// in a fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks,
+                                                           int64_t rows_per_block, int64_t N, int H, int Hp,
+                                                           float eps, float momentum,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var,
+                                                           float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd) {
+    __shared__ double sh[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool ok = c < H;
+    double acc = 0.0;
+    if (ok) {
+        for (int b = sl; b < nblocks; b += 16) {
+            const int64_t r0 = (int64_t)b * rows_per_block;
+            const double nb = (double)(min(N, r0 + rows_per_block) - r0);
+            acc += nb * (double)partial[((int64_t)b * 2) * Hp + c];
+        }
+    }
+    sh[sl][cl] = acc;
+    __syncthreads();
     double msum = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        const int64_t r0 = (int64_t)b * rows_per_block;
-        const double nb = (double)(min(N, r0 + rows_per_block) - r0);
-        msum += nb * (double)partial[((int64_t)b * 2) * Hp + c];
-    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) msum += sh[s][cl];
     const double mean = msum / (double)N;
-    double m2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
-        const int64_t r0 = (int64_t)b * rows_per_block;
-        const double nb = (double)(min(N, r0 + rows_per_block) - r0);
-        const double dm = (double)partial[((int64_t)b * 2) * Hp + c] - mean;
-        m2 += (double)partial[((int64_t)b * 2 + 1) * Hp + c] + nb * dm * dm;
+    __syncthreads();
+    acc = 0.0;
+    if (ok) {
+        for (int b = sl; b < nblocks; b += 16) {
+            const int64_t r0 = (int64_t)b * rows_per_block;
+            const double nb = (double)(min(N, r0 + rows_per_block) - r0);
+            const double dm = (double)partial[((int64_t)b * 2) * Hp + c] - mean;
+            acc += (double)partial[((int64_t)b * 2 + 1) * Hp + c] + nb * dm * dm;
+        }
     }
+    sh[sl][cl] = acc;
+    __syncthreads();
+    if (sl != 0 || !ok) return;
+    double m2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) m2 += sh[s][cl];
     if (m2 < 0.0) m2 = 0.0;
     const double var = m2 / (double)N;
     save_mean[c] = (float)mean;
@@ -248,17 +271,26 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
     }
 }
 
-__global__ void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H, int Hp,
-                                  float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= Hp) return;
-    double s1 = 0.0, s2 = 0.0;
+__global__ __launch_bounds__(256) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
+                                                         int Hp, float* __restrict__ sums,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh1[16][17];
+    __shared__ double sh2[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a1 = 0.0, a2 = 0.0;
     if (c < H) {
-        for (int b = 0; b < nblocks; ++b) {
-            s1 += (double)partial[((int64_t)b * 2 + 0) * Hp + c];
-            s2 += (double)partial[((int64_t)b * 2 + 1) * Hp + c];
+        for (int b = sl; b < nblocks; b += 16) {
+            a1 += (double)partial[((int64_t)b * 2 + 0) * Hp + c];
+            a2 += (double)partial[((int64_t)b * 2 + 1) * Hp + c];
         }
     }
+    sh1[sl][cl] = a1; sh2[sl][cl] = a2;
+    __syncthreads();
+    if (sl != 0 || c >= Hp) return;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { s1 += sh1[s][cl]; s2 += sh2[s][cl]; }
     sums[c] = (float)s1;
     sums[Hp + c] = (float)s2;
     if (c < H) {
@@ -310,9 +342,9 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.relu = relu; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
     a.mask = mask; a.seed = seed; a.offset = offset;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
-    // row ranges: aim at ~32 iterations per thread, at most 2048 workgroups
-    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 32);
-    if (nb > 2048) nb = 2048;
+    // row ranges: aim at ~64 iterations per thread, at most 1024 workgroups
+    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 64);
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     a.rows_per_block = hgv_cdiv(N, nb);
     *nblocks = (int)hgv_cdiv(N, a.rows_per_block);
@@ -345,7 +377,7 @@ extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(out, ldo, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
     else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 63) / 64), dim3(64), 0, stream, partial, nb, a.rows_per_block, N,
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 15) / 16), dim3(256), 0, stream, partial, nb, a.rows_per_block, N,
                        H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd);
     NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
     if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
@@ -387,7 +419,7 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(dy, lddy, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_stats<true>, dim3(nb), dim3(256), 0, stream, a, b, partial);
     else hipLaunchKernelGGL(k_ep_bwd_stats<false>, dim3(nb), dim3(256), 0, stream, a, b, partial);
-    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 63) / 64), dim3(64), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(256), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_apply<true>, dim3(nb), dim3(256), 0, stream, a, b);
     else hipLaunchKernelGGL(k_ep_bwd_apply<false>, dim3(nb), dim3(256), 0, stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd");

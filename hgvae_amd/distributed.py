@@ -1,0 +1,98 @@
+"""Data-parallel training: one process per GPU, one flat fp32 gradient bucket, one all-reduce.
+
+The reference is single-process (no distributed code anywhere); graphs of a mini-batch are
+disjoint components, so every kernel is rank-local and the only exchange is the gradient
+sum after backward.  The whole model is ~0.2-0.55 M parameters (0.8-2.2 MB): one contiguous
+``all_reduce`` (RCCL over xGMI with the ``nccl`` backend, ``gloo`` in CPU tests) is
+latency-bound and needs no overlap with backward.
+
+Parameters that received no gradient (e.g. the SAGPooling scorer, whose output the
+reference's train loop discards, autoencoder/vae_with_pool.py:154) contribute zeros.
+BatchNorm statistics stay rank-local (statistics over the nodes of the local shard).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Initialise torch.distributed from torchrun's environment. Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+class FlatGradBucket:
+    """Owns one contiguous buffer holding every parameter's gradient."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p, n in zip(self.params, sizes):
+            self.views.append(self.flat[off:off + n].view_as(p))
+            off += n
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.attach()
+
+    def attach(self) -> None:
+        """Point every ``p.grad`` at its slice of the flat buffer (autograd then accumulates in place)."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def zero(self) -> None:
+        """Replacement for ``optimizer.zero_grad()`` that keeps the views alive."""
+        self.flat.zero_()
+        self.attach()
+
+    def gather(self) -> None:
+        """Make the flat buffer hold the current gradients (zeros for parameters without one)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def all_reduce_mean(self) -> None:
+        """Sum the bucket over ranks and divide by the world size (no-op for one rank)."""
+        self.gather()
+        if self.world > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self.world)
+
+
+def all_reduce_scalar_mean(t: torch.Tensor, group=None) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.clone()
+        dist.all_reduce(t, group=group)
+        t /= dist.get_world_size(group)
+    return t
+
+
+def shard_range(num_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced split of ``num_items`` graphs over ``world`` ranks."""
+    base, rem = divmod(num_items, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))

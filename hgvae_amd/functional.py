@@ -30,7 +30,37 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # neighbour aggregation
 # --------------------------------------------------------------------------------------
+class LaunchProbe:
+    """Optional per-launch timing of the aggregation kernel with events on the launching stream."""
+
+    def __init__(self):
+        self.records = []  # (n_rows, F, E, weighted, start_event, end_event)
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [(n, f, e, w, s.elapsed_time(t)) for (n, f, e, w, s, t) in self.records]
+
+
+_probe: Optional[LaunchProbe] = None
+
+
+def set_probe(probe: Optional[LaunchProbe]) -> None:
+    global _probe
+    _probe = probe
+
+
 def _agg_launch(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out):
+    if _probe is not None:
+        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out)
+        t.record()
+        _probe.records.append((n_rows, F, csr.col.numel(), edge_w is not None or nbr_w is not None, s, t))
+        return
+    _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out)
+
+
+def _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out):
     _lib.call("hgv_agg_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), n_rows, x.data_ptr(), ld_of(x), F, row_mode,
               _lib.ptr(row_scale), _lib.ptr(edge_w), _lib.ptr(nbr_w), _lib.ptr(add),
               ld_of(add) if add is not None else 0, out.data_ptr(), ld_of(out), _lib.stream())
@@ -284,3 +314,151 @@ def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     if recon.shape != x.shape:
         raise _lib.HgvError(f"mse_loss: shapes differ {tuple(recon.shape)} vs {tuple(x.shape)}")
     return _MSE.apply(recon, x)
+
+
+# --------------------------------------------------------------------------------------
+# single-head graph attention (edge softmax + weighted aggregation)
+# --------------------------------------------------------------------------------------
+class _GatAggregate(torch.autograd.Function):
+    """out_i = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k]
+
+    over the loop-augmented graph ``lg``.  Inputs xw [N, C], a_src [N], a_dst [N].
+    """
+
+    @staticmethod
+    def forward(ctx, xw, a_src, a_dst, lg: Graph, slope, p, mask, seed, offset):
+        _lib.require_cuda(xw, a_src, a_dst)
+        xw = as_padded(xw)
+        a_src, a_dst = a_src.contiguous(), a_dst.contiguous()
+        n, e = lg.num_nodes, lg.num_edges
+        csr = lg.by_dst
+        alpha = torch.empty(e, dtype=torch.float32, device=xw.device)
+        alpha_drop = torch.empty(e, dtype=torch.float32, device=xw.device)
+        _lib.call("hgv_gat_softmax_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n,
+                  a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(slope), float(p), _lib.ptr(mask), seed, offset,
+                  alpha.data_ptr(), alpha_drop.data_ptr(), _lib.stream())
+        out = new_padded(n, xw.size(1), xw.device, zero_pad=False)
+        _agg_launch(csr, n, xw, xw.size(1), 0, None, alpha_drop, None, None, out)
+        ctx.lg, ctx.slope = lg, slope
+        ctx.save_for_backward(xw, a_src, a_dst, alpha, alpha_drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xw, a_src, a_dst, alpha, alpha_drop = ctx.saved_tensors
+        lg = ctx.lg
+        n, e, c = lg.num_nodes, lg.num_edges, xw.size(1)
+        g = as_padded(g)
+        csr, csr_t = lg.by_dst, lg.by_src
+        dev = xw.device
+        dad = torch.empty(e, dtype=torch.float32, device=dev)
+        dl = torch.empty(e, dtype=torch.float32, device=dev)
+        da_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.call("hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), n, g.data_ptr(), ld_of(g), xw.data_ptr(),
+                  ld_of(xw), c, a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(ctx.slope), alpha.data_ptr(),
+                  alpha_drop.data_ptr(), dad.data_ptr(), dl.data_ptr(), da_dst.data_ptr(), _lib.stream())
+        t2f = lg.src_pos_to_dst_pos
+        # d xw (direct path): transposed weighted aggregation of g
+        gxw = new_padded(n, c, dev, zero_pad=False)
+        _agg_launch(csr_t, n, g, c, 0, None, alpha_drop.index_select(0, t2f), None, None, gxw)
+        # d a_src[j] = sum of dl over the out-edges of j (F = 1 aggregation of ones with edge weights)
+        ones = torch.ones(n, 1, dtype=torch.float32, device=dev)
+        da_src = torch.empty(n, 1, dtype=torch.float32, device=dev)
+        _agg_launch(csr_t, n, ones, 1, 0, None, dl.index_select(0, t2f), None, None, da_src)
+        return gxw, da_src.view(n), da_dst, None, None, None, None, None, None
+
+
+def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, training: bool):
+    mask, seed, offset = None, 0, 0
+    if training and p > 0.0:
+        mask, seed, offset = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
+        if mask is not None:
+            mask = mask.view(-1)
+    else:
+        p = 0.0
+    return _GatAggregate.apply(xw, a_src, a_dst, loop_graph, slope, p, mask, seed, offset)
+
+
+# --------------------------------------------------------------------------------------
+# pooling helpers
+# --------------------------------------------------------------------------------------
+def topk_perm(score: torch.Tensor, ratio: float, batch: torch.Tensor, num_graphs: Optional[int] = None):
+    """Per-graph top ceil(ratio * n_g) nodes by descending score (ties: ascending node id)."""
+    _lib.require_cuda(score, batch)
+    n = score.numel()
+    if num_graphs is None:
+        num_graphs = int(batch.max().item()) + 1 if n else 0
+    n_g = torch.bincount(batch, minlength=num_graphs)
+    k_g = (float(ratio) * n_g.to(score.dtype)).ceil().to(torch.long)
+    ptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=score.device)
+    ptr[1:] = torch.cumsum(n_g, 0)
+    kptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=score.device)
+    kptr[1:] = torch.cumsum(k_g, 0)
+    total = int(kptr[-1].item())
+    perm = torch.empty(total, dtype=torch.long, device=score.device)
+    lib = _lib.load()
+    ws = _workspace(lib.hgv_topk_ws(n), score.device, "topk")
+    score = score.detach().contiguous().to(torch.float32)
+    _lib.call("hgv_topk_perm", score.data_ptr(), batch.data_ptr(), ptr.data_ptr(), k_g.data_ptr(), kptr.data_ptr(), n,
+              num_graphs, perm.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+    return perm
+
+
+def filter_adj(edge_index: torch.Tensor, edge_attr, perm: torch.Tensor, num_nodes: int):
+    """Edges with both ends in ``perm``, relabelled to positions in ``perm``, original order."""
+    _lib.require_cuda(edge_index, perm)
+    e = edge_index.size(1)
+    dev = edge_index.device
+    out = torch.empty(2, max(e, 1), dtype=torch.long, device=dev)
+    kept = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    ws = _workspace(lib.hgv_filter_adj_ws(e, num_nodes), dev, "filter_adj")
+    _lib.call("hgv_filter_adj", edge_index.data_ptr(), edge_index.stride(0), edge_index.stride(1), e, num_nodes,
+              perm.data_ptr(), perm.numel(), out.data_ptr(), out.stride(0), kept.data_ptr(), count.data_ptr(),
+              ws.data_ptr(), ws.numel(), _lib.stream())
+    m = int(count.item())  # the output size is data-dependent: one host sync, as in PyG
+    ei = out[:, :m]
+    ea = edge_attr.index_select(0, kept[:m].long()) if edge_attr is not None else None
+    return ei, ea
+
+
+class _GatherScale(torch.autograd.Function):
+    """out[q] = x[perm[q]] * scale[perm[q]]  (scale optional)."""
+
+    @staticmethod
+    def forward(ctx, x, perm, scale):
+        x = rowmajor(x)
+        k, f = perm.numel(), x.size(1)
+        out = new_padded(k, f, x.device)
+        s = scale.contiguous() if scale is not None else None
+        _lib.call("hgv_gather_rows", x.data_ptr(), ld_of(x), perm.data_ptr(), _lib.ptr(s), k, f, out.data_ptr(),
+                  ld_of(out), _lib.stream())
+        ctx.save_for_backward(x, perm, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, perm, s = ctx.saved_tensors
+        g = rowmajor(g)
+        k, f = perm.numel(), x.size(1)
+        need = ctx.needs_input_grad
+        gx = torch.zeros(x.size(0), f, dtype=torch.float32, device=x.device) if need[0] else None
+        gs = torch.zeros(x.size(0), dtype=torch.float32, device=x.device) if (s is not None and need[2]) else None
+        _lib.call("hgv_gather_rows_bwd", g.data_ptr(), ld_of(g), x.data_ptr(), ld_of(x), perm.data_ptr(), _lib.ptr(s),
+                  k, f, _lib.ptr(gx), f, _lib.ptr(gs), _lib.stream())
+        return gx, None, gs
+
+
+def gather_rows(x, perm, scale=None):
+    _lib.require_cuda(x, perm)
+    return _GatherScale.apply(x, perm, scale)
+
+
+def gather_i64(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """src[idx] for int64 vectors (batch[perm], perm[edge_index_cg])."""
+    _lib.require_cuda(src, idx)
+    src, flat = src.contiguous(), idx.contiguous().view(-1)
+    out = torch.empty_like(flat)
+    _lib.call("hgv_gather_i64", src.data_ptr(), flat.data_ptr(), flat.numel(), out.data_ptr(), _lib.stream())
+    return out.view(idx.shape)

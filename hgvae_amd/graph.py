@@ -177,10 +177,14 @@ def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
     if hit is not None:
         ref, version, n, g = hit
         if ref() is edge_index and version == edge_index._version and (num_nodes is None or n == num_nodes):
+            if torch.is_grad_enabled():
+                g.by_src  # the caller's tensor may be gone by the time backward runs
             return g
     if num_nodes is None:
         raise _lib.HgvError("num_nodes is required to build a Graph")
     g = Graph(edge_index, num_nodes, hold=False)
+    if torch.is_grad_enabled():
+        g.by_src  # built now: the caller's tensor may be gone by the time backward runs
     ref = weakref.ref(edge_index, lambda _r, k=key: _cache.pop(k, None))
     _cache[key] = (ref, edge_index._version, num_nodes, g)
     return g

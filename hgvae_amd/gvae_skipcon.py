@@ -4,4 +4,5 @@
 """
 from .data import CustomGraphDataset, collate_fn  # noqa: F401
 from .vae import SkipconVAE as VAE  # noqa: F401
+from .vae import PoolGraph, PoolUnpoolGraph  # noqa: F401
 from .vae import compute_rmsd, test_vae_rmsd, train_vae, validate_vae  # noqa: F401

@@ -62,3 +62,91 @@ class GraphConv(nn.Module):
         g = graph_of(edge_index, x.size(0))
         agg = Fn.aggregate(x, g, mean=False)
         return Fn.dual_linear(agg, self.lin_rel.weight, x, self.lin_root.weight, self.lin_rel.bias)
+
+
+class GCNConv(nn.Module):
+    """out = D^-1/2 (A + I) D^-1/2 (x W^T) + b with the degree taken over targets incl. self loops
+    (PyG GCNConv defaults: add_self_loops, normalize, unweighted edges)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        nn.init.xavier_uniform_(self.lin.weight)
+
+    def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
+        g = graph_of(edge_index, x.size(0)).with_self_loops()
+        dis = g.in_degree.to(torch.float32).pow(-0.5)  # >= 1 everywhere thanks to the loops
+        h = Fn.dual_linear(x, self.lin.weight)
+        h = h * dis.unsqueeze(1)
+        out = Fn.aggregate(h, g, mean=False)
+        return out * dis.unsqueeze(1) + self.bias
+
+
+class GATConv(nn.Module):
+    """Graph attention (PyG GATConv: concat=True, negative_slope=0.2, add_self_loops=True, bias).
+
+    Parameters follow PyG <= 2.3 naming (``lin_src`` and ``lin_dst`` share one weight);
+    a PyG >= 2.5 checkpoint with a single ``lin.weight`` is accepted on load.
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, dropout: float = 0.0,
+                 negative_slope: float = 0.2):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.dropout, self.negative_slope = dropout, negative_slope
+        self.lin_src = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_dst = self.lin_src
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        nn.init.xavier_uniform_(self.lin_src.weight)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        single = prefix + "lin.weight"
+        if single in state_dict:
+            w = state_dict.pop(single)
+            state_dict[prefix + "lin_src.weight"] = w
+            state_dict[prefix + "lin_dst.weight"] = w
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
+        n, h, c = x.size(0), self.heads, self.out_channels
+        lg = graph_of(edge_index, n).with_self_loops()
+        xw = Fn.dual_linear(x, self.lin_src.weight)
+        if h == 1:
+            a_src = torch.mv(xw, self.att_src.view(-1))
+            a_dst = torch.mv(xw, self.att_dst.view(-1))
+            out = Fn.gat_aggregate(xw, a_src, a_dst, lg, self.negative_slope, self.dropout, self.training)
+        else:
+            raise NotImplementedError(
+                "heads > 1 is not supported: the reference's encoder only type-checks with heads=1 "
+                "(gvae/gvae_skipcon_attention.py:74,96)")
+        return out + self.bias
+
+
+class SAGPooling(nn.Module):
+    """Self-attention graph pooling (PyG SAGPooling: ratio=0.5, GNN scorer -> tanh -> per-graph top-k).
+
+    Returns ``(x[perm] * score[perm], edge_index_cg, edge_attr_cg, batch[perm], perm, score[perm])``.
+    """
+
+    def __init__(self, in_channels: int, ratio: float = 0.5, GNN=GraphConv, **kwargs):
+        super().__init__()
+        self.in_channels, self.ratio = in_channels, ratio
+        self.gnn = GNN(in_channels, 1, **kwargs)
+
+    def forward(self, x, edge_index, edge_attr=None, batch=None):
+        n = x.size(0)
+        if batch is None:
+            batch = torch.zeros(n, dtype=torch.long, device=x.device)
+        raw_ei = edge_index.edge_index if isinstance(edge_index, Graph) else edge_index
+        score = torch.tanh(self.gnn(x, edge_index).reshape(-1))
+        perm = Fn.topk_perm(score, self.ratio, batch)
+        x_out = Fn.gather_rows(x, perm, score)
+        b_out = Fn.gather_i64(batch, perm)
+        ei_cg, ea_cg = Fn.filter_adj(raw_ei, edge_attr, perm, n)
+        return x_out, ei_cg, ea_cg, b_out, perm, score.index_select(0, perm)

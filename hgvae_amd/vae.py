@@ -17,7 +17,8 @@ from torch import nn
 
 from . import functional as Fn
 from .graph import as_padded, graph_of
-from .nn import SAGEConv
+from .data import Data
+from .nn import GATConv, GCNConv, GraphConv, SAGEConv, SAGPooling
 
 _pad_cache: "dict[int, tuple]" = {}
 
@@ -129,6 +130,184 @@ class SkipconVAE(_VAEBase):
 
     def recon_loss(self, x, reconstruction):
         return Fn.mse_loss(reconstruction, padded_input(x))
+
+
+class SkipconAttentionVAE(SkipconVAE):
+    """gvae/gvae_skipcon_attention.py:53-154: level 2 is relu(GATConv) -> BatchNorm1d; dropout 0.49."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, n_samples=10, heads=1):
+        self.heads = heads
+        super().__init__(in_channels, hidden_channels, out_channels, n_samples, dropout_prob=0.49)
+
+    def _make_level2(self, h, p):
+        return nn.Sequential(GATConv(h, h, heads=self.heads, dropout=p), nn.BatchNorm1d(h * self.heads))
+
+    def _level2(self, x1, g):
+        return self._finish(self.encoder2[0](x1, g), None, self.encoder2[1], relu=True)
+
+
+class PoolGraph(nn.Module):
+    """SAGPooling wrapper returning the coarse graph (gvae/gvae_skipcon.py:20-27)."""
+
+    def __init__(self, num_node_features, GNN=GraphConv):
+        super().__init__()
+        self.pool1 = SAGPooling(num_node_features, GNN=GNN)
+
+    def forward(self, x, edge_index, batch):
+        x, edge_index, _, batch, _, _ = self.pool1(x, edge_index, batch=batch)
+        return Data(x=x, edge_index=edge_index, batch=batch)
+
+
+class PoolUnpoolGraph(nn.Module):
+    """Pool, then map the coarse graph back onto original node ids (autoencoder/vae_with_pool.py:33-52)."""
+
+    def __init__(self, num_node_features, GNN=GraphConv):
+        super().__init__()
+        self.pool1 = SAGPooling(num_node_features, GNN=GNN)
+
+    def forward(self, x, edge_index, batch):
+        x_cg, ei_cg, _, _, perm, _ = self.pool1(x, edge_index, batch=batch)
+        new_batch = Fn.gather_i64(batch, perm)
+        x_unpooled = Fn.gather_rows(x, perm)
+        ei_unpooled = Fn.gather_i64(perm, ei_cg)
+        return x_unpooled, x_cg, ei_unpooled, new_batch
+
+
+class PoolVAE(_VAEBase):
+    """autoencoder/vae_with_pool.py:55-143: two SAGE levels, residual-add decoder, pool/unpool in forward."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, n_samples=10):
+        super().__init__()
+        h, z, p = hidden_channels, out_channels, 0.5
+        self.dropout_prob, self.n_samples, self.out_channels = p, n_samples, z
+        self.in_channels, self.hidden_channels = in_channels, h
+        self.encoder1 = nn.ModuleList([SAGEConv(in_channels, h), nn.Dropout(p), nn.BatchNorm1d(h)])
+        self.encoder2 = nn.ModuleList([SAGEConv(h, 2 * h), nn.Dropout(p), nn.BatchNorm1d(2 * h), SAGEConv(2 * h, 2 * z)])
+        self.decoder1 = nn.ModuleList([nn.Linear(z, h), nn.Dropout(p), nn.BatchNorm1d(h)])
+        self.decoder2 = nn.ModuleList([nn.Linear(h, in_channels)])
+        self._make_pools(h)
+
+    def _make_pools(self, h):
+        self.pool_graph = PoolGraph(h)
+        self.pool_unpool_graph = PoolUnpoolGraph(h)
+
+    def encode(self, x, edge_index):
+        g = graph_of(edge_index, x.size(0))
+        x = padded_input(x)
+        x1 = self._sage_level(self.encoder1, x, g)
+        x2 = self._sage_level(self.encoder2, x1, g)
+        mean, log_std = split_head(self.encoder2[3](x2, g), self.out_channels)
+        return x1, mean, log_std
+
+    def decode(self, z, x1):
+        d1 = self.decoder1
+        h = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=True)
+        return Fn.dual_linear(h + x1, self.decoder2[0].weight, None, None, self.decoder2[0].bias)
+
+    def forward(self, x, edge_index, batch):
+        x1, mean, log_std = self.encode(x, edge_index)
+        z = self.reparameterize(mean, log_std)
+        reconstruction = self.decode(z, x1)
+        x_unpooled, _, ei_unpooled, _ = self.pool_unpool_graph(x1, edge_index, batch)
+        return reconstruction, x_unpooled, ei_unpooled
+
+    def recon_loss(self, x, mean, log_std, edge_index, x1):
+        return Fn.mse_loss(self.decode(self.reparameterize(mean, log_std), x1), padded_input(x))
+
+
+class CoarsenGraph(nn.Module):
+    """GCNConv-scored SAGPooling returning (x_cg, edge_index_cg, n_cg) (autoencoder/vae_custom_pool.py:94-106).
+
+    The reference's pooling class also evaluates two dense-Laplacian Fiedler values per call
+    (vae_custom_pool.py:63-76); their difference lands in a tuple slot this wrapper drops, so it
+    never reaches an output.  ``spectral_probe=True`` evaluates it anyway with
+    ``torch.linalg.eigvalsh`` (O(N^3), off by default).
+    """
+
+    def __init__(self, num_node_features, alpha=0.5, spectral_probe=False):
+        super().__init__()
+        self.pool1 = SAGPooling(num_node_features, ratio=0.5, GNN=GCNConv)
+        self.alpha, self.spectral_probe = alpha, spectral_probe
+        self.last_spectral_loss = None
+
+    @staticmethod
+    def fiedler_value(edge_index, num_nodes):
+        """Second-smallest eigenvalue of I - D^-1/2 A D^-1/2, degree over SOURCES (vae_custom_pool.py:19-53)."""
+        dev = edge_index.device
+        deg = torch.zeros(num_nodes, device=dev).scatter_add_(0, edge_index[0], torch.ones(edge_index.size(1), device=dev))
+        dis = deg.pow(-0.5)
+        dis[torch.isinf(dis)] = 0
+        adj = torch.zeros(num_nodes, num_nodes, device=dev)
+        adj.index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.size(1), device=dev), accumulate=True)
+        lap = torch.eye(num_nodes, device=dev) - dis.view(-1, 1) * adj * dis.view(1, -1)
+        return torch.linalg.eigvalsh(lap)[1]
+
+    def forward(self, x, edge_index, batch):
+        x_cg, ei_cg, _, _, _, _ = self.pool1(x, edge_index, batch=batch)
+        if self.spectral_probe:
+            raw = edge_index.edge_index if not isinstance(edge_index, torch.Tensor) else edge_index
+            self.last_spectral_loss = self.alpha * (self.fiedler_value(raw, x.size(0))
+                                                    - self.fiedler_value(ei_cg, x_cg.size(0))).abs()
+        return x_cg, ei_cg, x_cg.size(0)
+
+
+class CustomPoolVAE(PoolVAE):
+    """autoencoder/vae_custom_pool.py:109-205: concat decoder with x1_transform, beta-weighted KL."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, n_samples=10, beta=0.5):
+        super().__init__(in_channels, hidden_channels, out_channels, n_samples)
+        self.beta = beta
+        self.decoder1[0] = nn.Linear(out_channels + in_channels, hidden_channels)
+        self.x1_transform = nn.Linear(hidden_channels, in_channels)
+
+    def _make_pools(self, h):
+        self.pool_graph = CoarsenGraph(h)
+        self.pool_unpool_graph = CoarsenGraph(h)
+
+    def decode(self, z, x1):
+        zt = self.x1_transform
+        x1_t = Fn.dual_linear(x1, zt.weight, None, None, zt.bias)
+        d1, zd = self.decoder1, self.out_channels
+        w = d1[0].weight
+        y = Fn.dual_linear(z, w[:, :zd], x1_t, w[:, zd:], d1[0].bias)
+        h = self._finish(y, d1[1], d1[2], relu=True)
+        return Fn.dual_linear(h, self.decoder2[0].weight, None, None, self.decoder2[0].bias)
+
+    def forward(self, x, edge_index, batch):
+        x1, mean, log_std = self.encode(x, edge_index)
+        z = self.reparameterize(mean, log_std)
+        reconstruction = self.decode(z, x1)
+        x_cg, ei_cg, _ = self.pool_unpool_graph(x1, edge_index, batch)
+        return reconstruction, x_cg, ei_cg, mean, log_std, x1
+
+    def recon_loss(self, x_recon, x_original, mean, log_std, edge_index, x1):
+        """Re-samples z and re-decodes; ``x_recon`` is ignored, as in the reference (:196-200)."""
+        return Fn.mse_loss(self.decode(self.reparameterize(mean, log_std), x1), padded_input(x_original))
+
+
+def train_vae_custom_pool(model, loader, optimizer, clip_value=None, device=None):
+    """autoencoder/vae_custom_pool.py:208-232: recon (re-sampled) + beta * kl, optional grad-norm clipping."""
+    if device is not None:
+        model.to(device)
+    model.train()
+    dev = model._device()
+    total = torch.zeros((), dtype=torch.float64, device=dev)
+    for data in loader:
+        data = _to_device(data, dev)
+        optimizer.zero_grad()
+        loss = custom_pool_step_loss(model, data.x, data.edge_index, data.batch)
+        loss.backward()
+        if clip_value is not None:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), clip_value)
+        optimizer.step()
+        total += loss.detach()
+    return float(total.item()) / len(loader)
+
+
+def custom_pool_step_loss(model, x, edge_index, batch):
+    reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
+    recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
+    return recon_loss + model.beta * model.kl_divergence(mean, log_std)
 
 
 def _to_device(data, device):

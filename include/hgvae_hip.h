@@ -112,6 +112,55 @@ int hgv_mse_fwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_
 int hgv_mse_bwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, const float* gout,
                 float* gr, int64_t ldg, hgv_stream_t stream);
 
+/* Exclusive prefix sum of int32 (in and out may alias). */
+size_t hgv_exclusive_scan_ws(int64_t n);
+int hgv_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes, hgv_stream_t stream);
+
+/* ---- single-head graph attention: GATConv(h, h, heads=1, dropout=0.49) at
+ *      gvae/gvae_skipcon_attention.py:68,109 (negative_slope 0.2, self loops added) ----------
+ * CSR = by-target CSR of the loop-augmented edge list (edges minus self loops, then one loop per
+ * node); perm maps CSR position -> index in that edge list (the index the dropout mask uses).
+ *   alpha[k]      = softmax over row i of leaky_relu(a_src[col[k]] + a_dst[i])  (+1e-16 in the sum)
+ *   alpha_drop[k] = alpha[k] * keep_k / (1-p)
+ * The output rows are hgv_agg_fwd(..., edge_w = alpha_drop).  a_src / a_dst are read with an
+ * element stride (ld_src / ld_dst) so one head of an [N, heads] table can be passed. */
+int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
+                        const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
+                        const uint8_t* mask, uint64_t seed, uint64_t offset, float* alpha, float* alpha_drop,
+                        hgv_stream_t stream);
+/* Backward: dad[k] = <g[i,:], xw[col[k],:]>; dl[k] = gradient w.r.t. the pre-leaky logit of edge k;
+ * da_dst[i] = sum_k dl[k].  (da_src is the sum of dl over each source's out-edges: hgv_agg_fwd on
+ * the by-source CSR with F = 1.)  dad is scratch [E']. */
+int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, int64_t N, const float* g, int64_t ldg, const float* xw,
+                int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst,
+                float slope, const float* alpha, const float* alpha_drop, float* dad, float* dl, float* da_dst,
+                hgv_stream_t stream);
+
+/* ---- SAGPooling: autoencoder/vae_with_pool.py:25,36,39 and :42-50;
+ *      autoencoder/vae_custom_pool.py:56-58 ------------------------------------------------
+ * hgv_topk_perm: per graph (ascending graph id) the k[g] highest-scoring nodes, descending score,
+ * ties by ascending node id.  batch [N], ptr [B+1], k [B], kptr [B+1] are int64 device arrays. */
+size_t hgv_topk_ws(int64_t N);
+int hgv_topk_perm(const float* score, const int64_t* batch, const int64_t* ptr, const int64_t* k,
+                  const int64_t* kptr, int64_t N, int64_t B, int64_t* perm, void* ws, size_t ws_bytes,
+                  hgv_stream_t stream);
+/* filter_adj: keep edges with both ends in perm, relabel to positions in perm, original order.
+ * out_ei: [2, cap] int64 (row stride ld_out, cap >= E suffices); kept_ids (nullable): original
+ * edge id of every kept edge; count[0]: number of kept edges. */
+size_t hgv_filter_adj_ws(int64_t E, int64_t N);
+int hgv_filter_adj(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int64_t E, int64_t N,
+                   const int64_t* perm, int64_t K, int64_t* out_ei, int64_t ld_out, int32_t* kept_ids,
+                   int32_t* count, void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* out[q,:] = x[idx[q],:] * (scale ? scale[idx[q]] : 1)   (x[perm] * score[perm], x[perm]) */
+int hgv_gather_rows(const float* x, int64_t ldx, const int64_t* idx, const float* scale, int64_t K, int F,
+                    float* out, int64_t ldo, hgv_stream_t stream);
+/* Backward: gx[idx[q],:] = g[q,:] * scale[idx[q]] (other rows untouched: caller zeroes gx),
+ * gscale[idx[q]] = <g[q,:], x[idx[q],:]>.  idx must hold distinct rows. */
+int hgv_gather_rows_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const int64_t* idx,
+                        const float* scale, int64_t K, int F, float* gx, int64_t ldgx, float* gscale,
+                        hgv_stream_t stream);
+int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* out, hgv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

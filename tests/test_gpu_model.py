@@ -143,3 +143,138 @@ def test_train_vae_loop_runs_and_learns():
     v = validate_vae(model, loader)
     r = test_vae_rmsd(model, loader)
     assert v == v and r == r and r > 0
+
+
+def _fresh_state(ref):
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    for k in state:
+        if k.endswith("running_mean"):
+            state[k].zero_()
+        elif k.endswith("running_var"):
+            state[k].fill_(1.0)
+        elif k.endswith("num_batches_tracked"):
+            state[k].zero_()
+    return state
+
+
+def _compare_step(ref, mod, loss_ref, loss, skip_grad=()):
+    close(loss, loss_ref, FWD_RTOL, what="loss")
+    ref_params = dict(ref.named_parameters())
+    for name, prm in mod.named_parameters():
+        rg = ref_params[name].grad
+        if rg is None:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        assert prm.grad is not None, name
+        close(prm.grad, rg, BWD_RTOL, what=name)
+    ref_bufs = dict(ref.named_buffers())
+    for name, buf in mod.named_buffers():
+        close(buf.float(), ref_bufs[name].float(), FWD_RTOL, what=name)
+
+
+def test_attention_train_step_matches_oracle():
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from hgvae_amd.vae import SkipconAttentionVAE, train_step_loss
+    gen = torch.Generator().manual_seed(10)
+    ei, n, batch = path_batch([138] * 3)
+    f_in, h, z, ns = 60, 256, 28, 10
+    x = torch.randn(n, f_in, generator=gen)
+    torch.manual_seed(10)
+    ref = OM.SkipconAttentionVAE(f_in, h, z, ns)
+    randomize_bn(ref, gen)
+    ref.train()
+    tape = skipcon_tape(n, h, z, ns, 0.49, gen, gat_edges=ei.size(1) + n)
+    state = _fresh_state(ref)
+    loss_ref = OM.skipcon_loss(ref, x, ei, batch, 1.0, O.NoiseTape(tape))[0]
+    loss_ref.backward()
+    dev = torch.device("cuda:0")
+    mod = SkipconAttentionVAE(f_in, h, z, ns)
+    mod.load_state_dict(state)
+    mod = mod.to(dev).train()
+    with use_noise(NoiseTape(tape)):
+        loss = train_step_loss(mod, x.to(dev), ei.to(dev), batch.to(dev), 1.0)
+    loss.backward()
+    _compare_step(ref, mod, loss_ref, loss)
+
+
+def pool_tape(n, h, z, ns, gen, second_encode=True, second_decode=False):
+    def m(*shape):
+        return torch.bernoulli(torch.full(shape, 0.5), generator=gen)
+    enc = lambda: [m(n, h), m(n, 2 * h)]  # noqa: E731
+    dec = lambda: [torch.randn(ns, n, z, generator=gen), m(n, h)]  # noqa: E731
+    items = enc() + dec()
+    if second_decode:
+        items += dec()
+    if second_encode:
+        items += enc()
+    return items
+
+
+def test_pool_vae_train_step_and_pool_outputs_match_oracle():
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from hgvae_amd.vae import PoolVAE, train_step_loss
+    gen = torch.Generator().manual_seed(20)
+    ei, n, batch = path_batch([454, 200, 91])
+    f_in, h, z, ns = 6, 138, 28, 10
+    x = torch.randn(n, f_in, generator=gen)
+    torch.manual_seed(20)
+    ref = OM.PoolVAE(f_in, h, z, ns)
+    randomize_bn(ref, gen)
+    ref.train()
+    tape = pool_tape(n, h, z, ns, gen)
+    state = _fresh_state(ref)
+    loss_ref = OM.pool_loss(ref, x, ei, batch, 1.0, O.NoiseTape(tape))[0]
+    loss_ref.backward()
+    dev = torch.device("cuda:0")
+    mod = PoolVAE(f_in, h, z, ns)
+    mod.load_state_dict(state)
+    mod = mod.to(dev).train()
+    with use_noise(NoiseTape(tape)):
+        loss = train_step_loss(mod, x.to(dev), ei.to(dev), batch.to(dev), 1.0)
+    loss.backward()
+    _compare_step(ref, mod, loss_ref, loss)
+    # the pool/unpool branch of forward (eval mode: no noise needed except eps)
+    ref.eval(); mod.eval()
+    eps = torch.randn(ns, n, z, generator=gen)
+    with torch.no_grad():
+        r_rec, r_xu, r_eiu = ref(x, ei, batch, O.NoiseTape([eps]))
+        with use_noise(NoiseTape([eps])):
+            o_rec, o_xu, o_eiu = mod(x.to(dev), ei.to(dev), batch.to(dev))
+    close(o_rec, r_rec, FWD_RTOL, what="recon")
+    assert torch.equal(o_eiu.cpu(), r_eiu)
+    close(o_xu, r_xu, FWD_RTOL, what="x_unpooled")
+
+
+def test_custom_pool_vae_train_step_matches_oracle():
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from hgvae_amd.vae import CustomPoolVAE, custom_pool_step_loss
+    gen = torch.Generator().manual_seed(30)
+    ei, n, batch = path_batch([300, 154])
+    f_in, h, z, ns = 6, 138, 28, 10
+    x = torch.randn(n, f_in, generator=gen)
+    torch.manual_seed(30)
+    ref = OM.CustomPoolVAE(f_in, h, z, ns, beta=0.5)
+    randomize_bn(ref, gen)
+    ref.train()
+    tape = pool_tape(n, h, z, ns, gen, second_encode=False, second_decode=True)
+    state = _fresh_state(ref)
+    loss_ref = OM.custom_pool_loss(ref, x, ei, batch, O.NoiseTape(tape))[0]
+    loss_ref.backward()
+    dev = torch.device("cuda:0")
+    mod = CustomPoolVAE(f_in, h, z, ns, beta=0.5)
+    mod.load_state_dict(state)
+    mod = mod.to(dev).train()
+    with use_noise(NoiseTape(tape)):
+        loss = custom_pool_step_loss(mod, x.to(dev), ei.to(dev), batch.to(dev))
+    loss.backward()
+    _compare_step(ref, mod, loss_ref, loss)
+    # coarse graph returned by forward
+    ref.eval(); mod.eval()
+    eps = torch.randn(ns, n, z, generator=gen)
+    with torch.no_grad():
+        r = ref(x, ei, batch, O.NoiseTape([eps]))
+        with use_noise(NoiseTape([eps])):
+            o = mod(x.to(dev), ei.to(dev), batch.to(dev))
+    close(o[0], r[0], FWD_RTOL, what="recon")
+    assert torch.equal(o[2].cpu(), r[2])
+    close(o[1], r[1], FWD_RTOL, what="x_cg")
