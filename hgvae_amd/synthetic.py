@@ -26,6 +26,7 @@ def _coil(n: int, gen: torch.Generator, device) -> torch.Tensor:
 def protein_like_graph(n: int, mean_degree: int, f_in: int, gen: torch.Generator, device) -> Data:
     pos = _coil(n, gen, device)
     d = torch.cdist(pos, pos)
+    d = torch.minimum(d, d.t())  # exactly symmetric, so every edge has its reverse
     d.fill_diagonal_(float("inf"))
     k = min(n * mean_degree, n * (n - 1))
     cutoff = torch.kthvalue(d.flatten(), k).values
