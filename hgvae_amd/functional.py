@@ -120,19 +120,48 @@ class _WeightedAggregate(torch.autograd.Function):
 # --------------------------------------------------------------------------------------
 # dense projection pair:  y = xa @ Wa^T + xb @ Wb^T + bias   (xb / Wb optional)
 # --------------------------------------------------------------------------------------
+MAX_GEMM_N = 288
+
+
+def _gemm_nt(xa, wa, wa_t: bool, xb, wb, bias, n_out: int) -> torch.Tensor:
+    """out[M, n_out] = xa @ op(wa)^T (+ xb @ op(wb)^T) (+ bias); op(w) = w ([n_out, K]) or, with
+    ``wa_t``, w^T (w is [K, n_out]).  xa / xb must already be in the padded layout."""
+    m = xa.size(0)
+    out = new_padded(m, n_out, xa.device, zero_pad=False)
+
+    def strides(w):
+        return (w.stride(1), w.stride(0)) if wa_t else (w.stride(0), w.stride(1))
+    sa = strides(wa)
+    sb = strides(wb) if xb is not None else (0, 0)
+    _lib.call("hgv_gemm_nt", xa.data_ptr(), ld_of(xa), xa.size(1), wa.data_ptr(), sa[0], sa[1],
+              _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0,
+              _lib.ptr(wb), sb[0], sb[1], _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
+    return out
+
+
+def _gemm_tn(g, x, want_bias: bool):
+    """(g^T @ x  [N, K] contiguous,  column sums of g or None); g, x in the padded layout."""
+    m, n, k = g.size(0), g.size(1), x.size(1)
+    gw = torch.empty(n, k, dtype=torch.float32, device=g.device)
+    gb = torch.empty(n, dtype=torch.float32, device=g.device) if want_bias else None
+    ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
+    _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), _lib.ptr(gb),
+              ws.data_ptr(), ws.numel(), _lib.stream())
+    return gw, gb
+
+
 class _DualLinear(torch.autograd.Function):
+    """y = xa @ Wa^T + xb @ Wb^T + bias on the fp32-MFMA kernels (xb / Wb / bias optional)."""
+
     @staticmethod
     def forward(ctx, xa, wa, xb, wb, bias):
         _lib.require_cuda(xa, wa)
-        xa = rowmajor(xa)
-        y = new_padded(xa.size(0), wa.size(0), xa.device)
-        if bias is not None:
-            torch.addmm(bias, xa, wa.t(), out=y)
-        else:
-            torch.mm(xa, wa.t(), out=y)
-        if xb is not None:
-            xb = rowmajor(xb)
-            torch.addmm(y, xb, wb.t(), out=y)
+        if wa.size(0) > MAX_GEMM_N or wa.size(1) > MAX_GEMM_N or (wb is not None and wb.size(1) > MAX_GEMM_N):
+            raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported "
+                                f"(got {tuple(wa.shape)}{'' if wb is None else ' and ' + str(tuple(wb.shape))})")
+        xa = as_padded(xa)
+        xb = as_padded(xb) if xb is not None else None
+        y = _gemm_nt(xa, wa, False, xb, wb, bias, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.save_for_backward(xa, wa, xb, wb)
         return y
@@ -140,23 +169,20 @@ class _DualLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         xa, wa, xb, wb = ctx.saved_tensors
-        g = rowmajor(g)
+        g = as_padded(g)
         need = ctx.needs_input_grad
         gxa = gwa = gxb = gwb = gb = None
+        want_bias = ctx.has_bias and need[4]
         if need[0]:
-            gxa = new_padded(g.size(0), wa.size(1), g.device)
-            torch.mm(g, wa, out=gxa)
-        if need[1]:
-            gwa = torch.mm(g.t(), xa)
+            gxa = _gemm_nt(g, wa, True, None, None, None, wa.size(1))
+        if need[1] or want_bias:
+            gwa, gb = _gemm_tn(g, xa, want_bias)
         if ctx.has_b:
             if need[2]:
-                gxb = new_padded(g.size(0), wb.size(1), g.device)
-                torch.mm(g, wb, out=gxb)
+                gxb = _gemm_nt(g, wb, True, None, None, None, wb.size(1))
             if need[3]:
-                gwb = torch.mm(g.t(), xb)
-        if ctx.has_bias and need[4]:
-            gb = g.sum(0)
-        return gxa, gwa, gxb, gwb, gb
+                gwb, _ = _gemm_tn(g, xb, False)
+        return gxa, gwa if need[1] else None, gxb, gwb, gb
 
 
 def dual_linear(xa, wa, xb=None, wb=None, bias=None):

@@ -415,3 +415,40 @@ def test_sag_pooling_matches_oracle(scorer):
             close(prm.grad, refp[name].grad, BWD_RTOL)
     else:
         pytest.fail("top-k order differs from the oracle on a seeded input without ties")
+
+
+# ------------------------------------------------------------------ fp32 MFMA projections
+GEMM_SHAPES = [  # (M, K1, K2, N)
+    (1, 6, None, 1), (127, 28, None, 138), (129, 138, 138, 138), (1000, 105, 105, 138), (777, 138, 138, 56),
+    (513, 276, 276, 56), (300, 138, 138, 276), (2049, 60, 60, 256), (640, 34, None, 138), (5000, 138, None, 105),
+]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+def test_dual_linear_forward_backward(shape):
+    """y = xa Wa^T + xb Wb^T + b on the MFMA kernels vs an fp64 CPU product (MFMA fp32 is an exact
+    fma chain, so the error is the usual fp32 accumulation error ~1e-7 * sum|a b|)."""
+    from hgvae_amd import functional as Fn
+    m, k1, k2, n = shape
+    gen = torch.Generator().manual_seed(m + n)
+    xa = torch.randn(m, k1, generator=gen, requires_grad=True)
+    wfull = torch.randn(n, k1 + (k2 or 0), generator=gen, requires_grad=True)   # one weight, two column slices
+    bias = torch.randn(n, generator=gen, requires_grad=True)
+    xb = torch.randn(m, k2, generator=gen, requires_grad=True) if k2 else None
+    gout = torch.randn(m, n, generator=gen)
+    xd = [t.detach().double().requires_grad_(True) if t is not None else None for t in (xa, wfull, bias, xb)]
+    ref = xd[0] @ xd[1][:, :k1].t() + xd[2]
+    if k2:
+        ref = ref + xd[3] @ xd[1][:, k1:].t()
+    ref.backward(gout.double())
+    dv = [t.detach().to(dev()).requires_grad_(True) if t is not None else None for t in (xa, wfull, bias, xb)]
+    out = Fn.dual_linear(dv[0], dv[1][:, :k1], dv[3], dv[1][:, k1:] if k2 else None, dv[2])
+    out.backward(gout.to(dev()))
+    close(out, ref, 2e-6)
+    for got, want in zip(dv, xd):
+        if got is not None:
+            close(got.grad, want.grad, 5e-6)
+    # pad columns of the output buffer are zero
+    if n % 4:
+        base = out.as_strided((m, (n + 3) // 4 * 4), (out.stride(0), 1))
+        assert float(base[:, n:].abs().max()) == 0.0
