@@ -57,73 +57,84 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const GemmArgs g) {
     float rw[2 * NT];
     const int a_c4 = t & 7, a_r = t >> 3;
 
+    // Loads are unconditional on clamped (always valid) addresses; invalid elements are removed by
+    // MULTIPLYING with a 0/1 mask when the registers are written to LDS.  (A select "valid ? v : 0"
+    // lets the compiler sink each load under its own branch with its own wait, and masking right
+    // after the load would force the wait ahead of the MFMAs the load is meant to overlap.)
+    // Rows past M reuse row M-1: their results are never stored.
     auto load_chunk = [&](const GemmSrc& s, int kc) {
-        const int kb = kc + 4 * a_c4;
+        const int kb_c = min(kc + 4 * a_c4, ((s.K - 1) >> 2) << 2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t row = row0 + a_r + 32 * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < g.M && kb < s.K) {
-                v = *reinterpret_cast<const float4*>(s.A + row * s.lda + kb);
-                if (kb + 1 >= s.K) v.y = 0.f;
-                if (kb + 2 >= s.K) v.z = 0.f;
-                if (kb + 3 >= s.K) v.w = 0.f;
-            }
-            ra[q] = v;
+            const int64_t row_c = min(row0 + a_r + 32 * q, g.M - 1);
+            ra[q] = *reinterpret_cast<const float4*>(s.A + row_c * s.lda + kb_c);
         }
 #pragma unroll
         for (int q = 0; q < 2 * NT; ++q) {
             const int e = t + 256 * q;
             int n, k;
             if (s.sk == 1) { k = e & 31; n = e >> 5; } else { n = e % (NT * 16); k = e / (NT * 16); }
-            float v = 0.f;
-            if (n < g.N && kc + k < s.K) v = s.W[(int64_t)n * s.sn + (int64_t)(kc + k) * s.sk];
-            rw[q] = v;
+            const int n_c = min(n, g.N - 1), k_c = min(kc + k, s.K - 1);
+            rw[q] = s.W[(int64_t)n_c * s.sn + (int64_t)k_c * s.sk];
         }
     };
-    auto store_chunk = [&](const GemmSrc& s) {
+    auto store_chunk = [&](const GemmSrc& s, int kc) {
+        const int kb = kc + 4 * a_c4;
+        const float m0 = kb + 0 < s.K ? 1.f : 0.f, m1 = kb + 1 < s.K ? 1.f : 0.f;
+        const float m2 = kb + 2 < s.K ? 1.f : 0.f, m3 = kb + 3 < s.K ? 1.f : 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(&As[(a_r + 32 * q) * G_LD + 4 * a_c4]) = ra[q];
+        for (int q = 0; q < 4; ++q) {
+            float4 v = ra[q];
+            v.x *= m0; v.y *= m1; v.z *= m2; v.w *= m3;
+            *reinterpret_cast<float4*>(&As[(a_r + 32 * q) * G_LD + 4 * a_c4]) = v;
+        }
 #pragma unroll
         for (int q = 0; q < 2 * NT; ++q) {
             const int e = t + 256 * q;
             int n, k;
             if (s.sk == 1) { k = e & 31; n = e >> 5; } else { n = e % (NT * 16); k = e / (NT * 16); }
-            Ws[n * G_LD + k] = rw[q];
+            const float mk = (n < g.N && kc + k < s.K) ? 1.f : 0.f;
+            Ws[n * G_LD + k] = rw[q] * mk;
         }
     };
 
-    for (int si = 0; si < g.nsrc; ++si) {
-        const GemmSrc s = g.s[si];
-        const int nchunks = (s.K + G_KC - 1) / G_KC;
-        load_chunk(s, 0);
-        for (int c = 0; c < nchunks; ++c) {
-            __syncthreads();            // previous chunk fully consumed
-            store_chunk(s);
-            __syncthreads();
-            if (c + 1 < nchunks) load_chunk(s, (c + 1) * G_KC);   // in flight during the MFMAs below
-            const int kvalid = min(G_KC, s.K - c * G_KC);
+    auto compute = [&](int kvalid) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (16 * u < kvalid) {
-                    f32x4 a[2];
+        for (int u = 0; u < 2; ++u) {
+            if (16 * u < kvalid) {
+                f32x4 a[2];
 #pragma unroll
-                    for (int rt = 0; rt < 2; ++rt)
-                        a[rt] = *reinterpret_cast<const f32x4*>(&As[(32 * w + 16 * rt + i) * G_LD + 16 * u + 4 * kq]);
+                for (int rt = 0; rt < 2; ++rt)
+                    a[rt] = *reinterpret_cast<const f32x4*>(&As[(32 * w + 16 * rt + i) * G_LD + 16 * u + 4 * kq]);
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(16 * nt + i) * G_LD + 16 * u + 4 * kq]);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(16 * nt + i) * G_LD + 16 * u + 4 * kq]);
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) {
-                            acc[0][nt] = MFMA16(a[0][m], b[m], acc[0][nt]);
-                            acc[1][nt] = MFMA16(a[1][m], b[m], acc[1][nt]);
-                        }
+                    for (int m = 0; m < 4; ++m) {
+                        acc[0][nt] = MFMA16(a[0][m], b[m], acc[0][nt]);
+                        acc[1][nt] = MFMA16(a[1][m], b[m], acc[1][nt]);
                     }
                 }
             }
         }
+    };
+
+    // Software pipeline without loop-carried staging registers: an iteration issues the global loads
+    // of chunk c, runs the MFMAs of chunk c-1 out of LDS while they fly, then swaps chunk c into LDS.
+    int kvalid_prev = 0;
+    for (int si = 0; si < g.nsrc; ++si) {
+        const GemmSrc s = g.s[si];
+        const int nchunks = (s.K + G_KC - 1) / G_KC;
+        for (int c = 0; c < nchunks; ++c) {
+            load_chunk(s, c * G_KC);
+            if (kvalid_prev > 0) compute(kvalid_prev);
+            __syncthreads();
+            store_chunk(s, c * G_KC);
+            __syncthreads();
+            kvalid_prev = min(G_KC, s.K - c * G_KC);
+        }
     }
+    compute(kvalid_prev);
 
     // epilogue: D layout of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll
@@ -181,59 +192,49 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const WgArgs g) {
     constexpr int GQ = (GV + 255) / 256, AQ = (AV + 255) / 256;
     float4 rg[GQ], ra[AQ];
 
+    const int n_last = ((g.N - 1) >> 2) << 2, k_last = ((g.K - 1) >> 2) << 2;
+    // unconditional loads on clamped addresses; invalid elements are multiplied by a 0 mask when the
+    // registers go to LDS (see k_gemm_nt)
     auto load_stage = [&](int64_t m0) {
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int e = min(t + 256 * q, GV - 1);
+            const int r = e / (NB / 4), c4 = e - r * (NB / 4);
+            rg[q] = *reinterpret_cast<const float4*>(g.G + min(m0 + r, g.M - 1) * g.ldg + min(n_base + 4 * c4, n_last));
+        }
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int e = min(t + 256 * q, AV - 1);
+            const int r = e / (KB / 4), c4 = e - r * (KB / 4);
+            ra[q] = *reinterpret_cast<const float4*>(g.A + min(m0 + r, g.M - 1) * g.lda + min(k_base + 4 * c4, k_last));
+        }
+    };
+    auto store_stage = [&](int64_t m0) {
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int e = t + 256 * q;
             const int r = e / (NB / 4), c4 = e - r * (NB / 4);
             const int col = n_base + 4 * c4;
-            const int64_t row = m0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < GV && row < m_hi && col < g.N) {
-                v = *reinterpret_cast<const float4*>(g.G + row * g.ldg + col);
-                if (col + 1 >= g.N) v.y = 0.f;
-                if (col + 2 >= g.N) v.z = 0.f;
-                if (col + 3 >= g.N) v.w = 0.f;
-            }
-            rg[q] = v;
+            const float rm = m0 + r < m_hi ? 1.f : 0.f;
+            float4 v = rg[q];
+            v.x *= (col + 0 < g.N ? rm : 0.f); v.y *= (col + 1 < g.N ? rm : 0.f);
+            v.z *= (col + 2 < g.N ? rm : 0.f); v.w *= (col + 3 < g.N ? rm : 0.f);
+            if (e < GV) *reinterpret_cast<float4*>(&Gs[r * GS_LD + 4 * c4]) = v;
         }
 #pragma unroll
         for (int q = 0; q < AQ; ++q) {
             const int e = t + 256 * q;
             const int r = e / (KB / 4), c4 = e - r * (KB / 4);
             const int col = k_base + 4 * c4;
-            const int64_t row = m0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < AV && row < m_hi && col < g.K) {
-                v = *reinterpret_cast<const float4*>(g.A + row * g.lda + col);
-                if (col + 1 >= g.K) v.y = 0.f;
-                if (col + 2 >= g.K) v.z = 0.f;
-                if (col + 3 >= g.K) v.w = 0.f;
-            }
-            ra[q] = v;
-        }
-    };
-    auto store_stage = [&]() {
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const int e = t + 256 * q;
-            const int r = e / (NB / 4), c4 = e - r * (NB / 4);
-            if (e < GV) *reinterpret_cast<float4*>(&Gs[r * GS_LD + 4 * c4]) = rg[q];
-        }
-#pragma unroll
-        for (int q = 0; q < AQ; ++q) {
-            const int e = t + 256 * q;
-            const int r = e / (KB / 4), c4 = e - r * (KB / 4);
-            if (e < AV) *reinterpret_cast<float4*>(&As[r * AS_LD + 4 * c4]) = ra[q];
+            const float rm = m0 + r < m_hi ? 1.f : 0.f;
+            float4 v = ra[q];
+            v.x *= (col + 0 < g.K ? rm : 0.f); v.y *= (col + 1 < g.K ? rm : 0.f);
+            v.z *= (col + 2 < g.K ? rm : 0.f); v.w *= (col + 3 < g.K ? rm : 0.f);
+            if (e < AV) *reinterpret_cast<float4*>(&As[r * AS_LD + 4 * c4]) = v;
         }
     };
 
-    if (m_lo < m_hi) load_stage(m_lo);
-    for (int64_t m0 = m_lo; m0 < m_hi; m0 += T_BM) {
-        __syncthreads();
-        store_stage();
-        __syncthreads();
-        if (m0 + T_BM < m_hi) load_stage(m0 + T_BM);
+    auto compute = [&]() {
         if (g.bias_partial && blockIdx.y == 0 && t < NB) {
 #pragma unroll 8
             for (int r = 0; r < T_BM; ++r) bsum += Gs[r * GS_LD + t];
@@ -246,11 +247,26 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const WgArgs g) {
 #pragma unroll
             for (int b = 0; b < KT; ++b) ab[b] = As[(4 * st + kq) * AS_LD + 16 * b + i];
 #pragma unroll
-            for (int a = 0; a < NTW; ++a)
+            for (int a = 0; a < NTW; ++a) {
+                if (n_base + 16 * (w + 4 * a) < g.N) {   // wave-uniform: tiles past N hold zeros
 #pragma unroll
-                for (int b = 0; b < KT; ++b) acc[a][b] = MFMA16(ga[a], ab[b], acc[a][b]);
+                    for (int b = 0; b < KT; ++b) acc[a][b] = MFMA16(ga[a], ab[b], acc[a][b]);
+                }
+            }
         }
+    };
+
+    // same pipeline shape as k_gemm_nt: load stage s, compute stage s-1, swap
+    bool have = false;
+    for (int64_t m0 = m_lo; m0 < m_hi; m0 += T_BM) {
+        load_stage(m0);
+        if (have) compute();
+        __syncthreads();
+        store_stage(m0);
+        __syncthreads();
+        have = true;
     }
+    if (have) compute();
 
     float* out = g.partial + (int64_t)blockIdx.x * g.N * g.K;
 #pragma unroll
@@ -269,14 +285,30 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const WgArgs g) {
         g.bias_partial[(int64_t)blockIdx.x * g.N + n_base + t] = bsum;
 }
 
-// out[e] = sum over slices of partial[s][e], fixed order
+// out[e] = sum over slices of partial[s][e].  A workgroup handles 32 elements x 8 slice groups;
+// group sums are combined through LDS in a fixed order, so the result is reproducible.
 __global__ __launch_bounds__(256) void k_reduce_slices(const float* __restrict__ partial, int slices, int64_t count,
                                                        float* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= count) return;
-    double s = 0.0;
-    for (int k = 0; k < slices; ++k) s += (double)partial[(int64_t)k * count + e];
-    out[e] = (float)s;
+    __shared__ double sh[8][33];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + el;
+    double s0 = 0.0, s1 = 0.0;
+    if (e < count) {
+        int k = grp;
+        for (; k + 8 < slices; k += 16) {
+            s0 += (double)partial[(int64_t)k * count + e];
+            s1 += (double)partial[(int64_t)(k + 8) * count + e];
+        }
+        if (k < slices) s0 += (double)partial[(int64_t)k * count + e];
+    }
+    sh[grp][el] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && e < count) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += sh[q][el];
+        out[e] = (float)s;
+    }
 }
 
 template <int NT>
@@ -373,9 +405,9 @@ extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, i
     HGV_TN(3, 2) HGV_TN(3, 4) HGV_TN(3, 7) HGV_TN(3, 9)
 #undef HGV_TN
     const int64_t cnt = (int64_t)N * K;
-    hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(cnt, 256)), dim3(256), 0, stream, g.partial, slices, cnt, GW);
+    hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(cnt, 32)), dim3(256), 0, stream, g.partial, slices, cnt, GW);
     if (gbias)
-        hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(N, 256)), dim3(256), 0, stream, g.bias_partial, slices,
+        hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(N, 32)), dim3(256), 0, stream, g.bias_partial, slices,
                            (int64_t)N, gbias);
     HGV_CHECK_LAUNCH("gemm_tn");
     return HGV_OK;
