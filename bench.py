@@ -33,6 +33,17 @@ def agg_bytes(n, f, e):
     return 4 * f * e + 4 * f * n + 4 * e + 4 * (n + 1)
 
 
+def measured_traffic(workload, f):
+    """HBM bytes per aggregation launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
+    calibrated on a copy of known size); None when no summary exists for this workload / width."""
+    path = os.path.join(ROOT, "profiles", f"agg_pmc_{workload}.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    return d["agg_fwd"]["hbm_bytes_per_launch"] if d.get("F") == f else None
+
+
 def build_workload(name, rank, device):
     from hgvae_amd import synthetic
     if name == "protein256":
@@ -139,6 +150,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (diagnostic only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,7 +178,7 @@ def main():
             achieved = agg_bytes(n_nodes, h, n_edges) / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_aggregate<4,false> (mean aggregation, F=%d)" % h,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, h),
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": len(dom),
                     "algorithmic_bytes_per_launch": agg_bytes(n_nodes, h, n_edges),
                     "all_aggregations_GBps": round(allb / (allms * 1e-3) / 1e9, 1) if allms > 0 else None}
@@ -183,6 +195,7 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-3"},
             "edge_messages_per_s": round(14 * tot_edges * args.steps / elapsed, 1),
             "loss": round(float(loss.item()), 6),
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
