@@ -123,19 +123,45 @@ class _WeightedAggregate(torch.autograd.Function):
 MAX_GEMM_N = 288
 
 
+_pack_cache: "dict[tuple, tuple]" = {}
+
+
+def _packed(w: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """Packed image of a weight (or of its transpose) for the NT kernel.
+
+    Cached per (base tensor object, view geometry) and refreshed when the tensor's version
+    changes, so a weight used by both encode passes (and again in backward) is packed once per
+    optimizer step into a buffer that is reused across steps.
+    """
+    import weakref
+    base = w._base if w._base is not None else w
+    key = (id(base), w.storage_offset(), tuple(w.stride()), tuple(w.shape), transposed, w.device.index)
+    hit = _pack_cache.get(key)
+    version = base._version
+    if hit is not None and hit[0]() is base:
+        if hit[1] == (version, w.data_ptr()):
+            return hit[2]
+        buf = hit[2]
+    else:
+        n, k = (w.size(1), w.size(0)) if transposed else (w.size(0), w.size(1))
+        buf = torch.empty(_lib.load().hgv_pack_bytes(n, k) // 4, dtype=torch.float32, device=w.device)
+    n, k = (w.size(1), w.size(0)) if transposed else (w.size(0), w.size(1))
+    sn, sk = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+    _lib.call("hgv_pack_weight", w.data_ptr(), sn, sk, n, k, buf.data_ptr(), _lib.stream())
+    _pack_cache[key] = (weakref.ref(base, lambda _r, kk=key: _pack_cache.pop(kk, None)), (version, w.data_ptr()), buf)
+    return buf
+
+
 def _gemm_nt(xa, wa, wa_t: bool, xb, wb, bias, n_out: int) -> torch.Tensor:
     """out[M, n_out] = xa @ op(wa)^T (+ xb @ op(wb)^T) (+ bias); op(w) = w ([n_out, K]) or, with
     ``wa_t``, w^T (w is [K, n_out]).  xa / xb must already be in the padded layout."""
     m = xa.size(0)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
-
-    def strides(w):
-        return (w.stride(1), w.stride(0)) if wa_t else (w.stride(0), w.stride(1))
-    sa = strides(wa)
-    sb = strides(wb) if xb is not None else (0, 0)
-    _lib.call("hgv_gemm_nt", xa.data_ptr(), ld_of(xa), xa.size(1), wa.data_ptr(), sa[0], sa[1],
-              _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0,
-              _lib.ptr(wb), sb[0], sb[1], _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
+    pa = _packed(wa, wa_t)
+    pb = _packed(wb, wa_t) if xb is not None else None
+    _lib.call("hgv_gemm_nt_packed", xa.data_ptr(), ld_of(xa), xa.size(1), pa.data_ptr(),
+              _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, _lib.ptr(pb),
+              _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
     return out
 
 

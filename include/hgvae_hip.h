@@ -166,12 +166,21 @@ int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* o
  * hgv_gemm_nt:  C[M,N] = A1[M,K1] W1^T (+ A2[M,K2] W2^T) (+ bias[N]);  weight element (n,k) of source s
  * is read at Ws[n*sn_s + k*sk_s] ((ld,1): row-major [N,K] weight; (1,ld): multiply by a row-major [K,N]
  * matrix, i.e. the grad-input product).  A2 may be null.  A1/A2: 16-byte aligned, lda % 4 == 0,
- * lda >= ceil(K/4)*4.  Columns [N, ldc) of C are written as zeros.  N <= 288.
+ * lda >= ceil(K/4)*4, pad columns [K, lda) finite.  Columns [N, ldc) of C are written as zeros.  N <= 288.
+ * The weights are first packed into ws (hgv_gemm_nt_ws bytes); callers that reuse a weight can pack once
+ * with hgv_pack_weight (hgv_pack_bytes bytes per weight) and call hgv_gemm_nt_packed.
  * hgv_gemm_tn:  GW[N,K] (contiguous) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
  * Reduction over M is split over workgroups and combined in a fixed order (reproducible). */
+int hgv_pack_rows(int N);
+size_t hgv_pack_bytes(int N, int K);
+int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, hgv_stream_t stream);
+int hgv_gemm_nt_packed(const float* A1, int64_t lda1, int K1, const float* Wp1, const float* A2, int64_t lda2, int K2,
+                       const float* Wp2, const float* bias, int64_t M, int N, float* C, int64_t ldc,
+                       hgv_stream_t stream);
+size_t hgv_gemm_nt_ws(int N, int K1, int K2);
 int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W1, int64_t sn1, int64_t sk1, const float* A2,
                 int64_t lda2, int K2, const float* W2, int64_t sn2, int64_t sk2, const float* bias, int64_t M, int N,
-                float* C, int64_t ldc, hgv_stream_t stream);
+                float* C, int64_t ldc, void* ws, size_t ws_bytes, hgv_stream_t stream);
 size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
                 float* gbias, void* ws, size_t ws_bytes, hgv_stream_t stream);
