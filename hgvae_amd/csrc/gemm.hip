@@ -40,6 +40,16 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ W
     }
 }
 
+// rows [row_offset, row_offset + N) of a packed image whose other rows the caller keeps zero
+__global__ __launch_bounds__(256) void k_pack_weight_rows(const float* __restrict__ W, int64_t sn, int64_t sk, int N,
+                                                          int K, float* __restrict__ out, int row_offset, int Kp) {
+    const int64_t total = (int64_t)N * Kp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(e / Kp), k = (int)(e - (int64_t)n * Kp);
+        out[(int64_t)(row_offset + n) * Kp + k] = k < K ? W[(int64_t)n * sn + (int64_t)k * sk] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NT kernel on packed weights
 // ------------------------------------------------------------------------------------------
@@ -370,6 +380,21 @@ extern "C" int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, in
     const int64_t total = (int64_t)rows * Kp;
     hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, W, sn, sk, N, K, out, rows, Kp);
     HGV_CHECK_LAUNCH("pack_weight");
+    return HGV_OK;
+}
+
+// Writes one weight into rows [row_offset, row_offset + N) of a packed image that holds several
+// weights stacked along N (e.g. [W_l ; W_r] so that one product yields both halves).  The image has
+// hgv_pack_rows(total N) rows of ceil(K/32)*32 floats; rows not covered by any weight must be zero
+// (zero the buffer once when it is allocated).
+extern "C" int hgv_pack_weight_rows(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, int row_offset,
+                                    hipStream_t stream) {
+    HGV_REQUIRE(W && out && N > 0 && K > 0 && row_offset >= 0, HGV_EINVAL, "pack_weight_rows: bad arguments");
+    HGV_REQUIRE(row_offset + N <= 288, HGV_EUNSUPPORTED, "pack_weight_rows: more than 288 rows");
+    const int Kp = kp_of(K);
+    hipLaunchKernelGGL(k_pack_weight_rows, dim3((unsigned)hgv_cdiv((int64_t)N * Kp, 256)), dim3(256), 0, stream, W, sn, sk,
+                       N, K, out, row_offset, Kp);
+    HGV_CHECK_LAUNCH("pack_weight_rows");
     return HGV_OK;
 }
 

@@ -211,6 +211,98 @@ class _DualLinear(torch.autograd.Function):
         return gxa, gwa if need[1] else None, gxb, gwb, gb
 
 
+def _packed_stack(wl: torch.Tensor, wr: torch.Tensor) -> torch.Tensor:
+    """Packed image of [wl ; wr] stacked along the output dimension (both [n_out, K])."""
+    import weakref
+    key = ("stack", id(wl), id(wr), tuple(wl.shape), wl.device.index)
+    sig = (wl._version, wr._version, wl.data_ptr(), wr.data_ptr())
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0]() is wl and hit[1] == sig:
+        return hit[2]
+    n, k = wl.size(0), wl.size(1)
+    if hit is not None and hit[0]() is wl:
+        buf = hit[2]
+    else:
+        buf = torch.zeros(_lib.load().hgv_pack_bytes(2 * n, k) // 4, dtype=torch.float32, device=wl.device)
+    for w, off in ((wl, 0), (wr, n)):
+        _lib.call("hgv_pack_weight_rows", w.data_ptr(), w.stride(0), w.stride(1), n, k, buf.data_ptr(), off,
+                  _lib.stream())
+    _pack_cache[key] = (weakref.ref(wl, lambda _r, kk=key: _pack_cache.pop(kk, None)), sig, buf)
+    return buf
+
+
+class _SageConv(torch.autograd.Function):
+    """y = lin_l(aggregate(x)) + lin_r(x) as one operator (SAGEConv / GraphConv).
+
+    When the output is narrower than the input the projection runs first (one product with the
+    stacked weight [W_l ; W_r]) and the aggregation works on the narrow result: aggregation is
+    linear, so this equals aggregate-then-project up to fp32 rounding and moves fewer bytes.
+    The backward pass returns a single padded gradient for x (the add of the aggregation path and
+    the root path is fused into the aggregation kernel).
+    """
+
+    @staticmethod
+    def forward(ctx, x, wl, bl, wr, graph: Graph, mean: bool):
+        _lib.require_cuda(x, wl, wr)
+        n_out, n_in = wl.shape
+        if max(n_out, n_in) > MAX_GEMM_N:
+            raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported (got {tuple(wl.shape)})")
+        x = as_padded(x)
+        n = graph.num_nodes
+        first = n_out < n_in and 2 * n_out <= MAX_GEMM_N
+        if first:
+            tr = new_padded(n, 2 * n_out, x.device, zero_pad=False)
+            bias2 = torch.cat([torch.zeros_like(bl), bl]) if bl is not None else None
+            _lib.call("hgv_gemm_nt_packed", x.data_ptr(), ld_of(x), n_in, _packed_stack(wl, wr).data_ptr(), None, 0, 0,
+                      None, _lib.ptr(bias2), n, 2 * n_out, tr.data_ptr(), ld_of(tr), _lib.stream())
+            y = new_padded(n, n_out, x.device)
+            _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
+            ctx.save_for_backward(x, wl, wr)
+        else:
+            agg = new_padded(n, n_in, x.device, zero_pad=False)
+            _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
+            y = _gemm_nt(agg, wl, False, x, wr, bl, n_out)
+            ctx.save_for_backward(x, wl, wr, agg)
+        ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        graph, mean = ctx.graph, ctx.mean
+        n = graph.num_nodes
+        g = as_padded(g)
+        need = ctx.needs_input_grad
+        want_bias = ctx.has_bias and need[2]
+        inv = graph.inv_deg if mean else None
+        gx = None
+        if ctx.first:
+            x, wl, wr = ctx.saved_tensors
+            n_out, n_in = wl.shape
+            gt = new_padded(n, n_out, g.device, zero_pad=False)      # gradient of the aggregated half
+            _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
+            gwl, _ = _gemm_tn(gt, x, False)
+            gwr, gb = _gemm_tn(g, x, want_bias)
+            if need[0]:
+                gx = _gemm_nt(gt, wl, True, g, wr, None, n_in)
+        else:
+            x, wl, wr, agg = ctx.saved_tensors
+            n_out, n_in = wl.shape
+            gwl, gb = _gemm_tn(g, agg, want_bias)
+            gwr, _ = _gemm_tn(g, x, False)
+            if need[0]:
+                t = _gemm_nt(g, wl, True, None, None, None, n_in)
+                gr = _gemm_nt(g, wr, True, None, None, None, n_in)
+                gx = new_padded(n, n_in, g.device, zero_pad=False)
+                _agg_launch(graph.by_src, n, t, n_in, 0, None, None, inv, gr, gx)
+        return gx, gwl, gb, gwr, None, None
+
+
+def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True):
+    if x.size(0) != graph.num_nodes:
+        raise _lib.HgvError(f"x has {x.size(0)} rows but the graph has {graph.num_nodes} nodes")
+    return _SageConv.apply(x, wl, bl, wr, graph, mean)
+
+
 def dual_linear(xa, wa, xb=None, wb=None, bias=None):
     return _DualLinear.apply(xa, wa, xb, wb, bias)
 

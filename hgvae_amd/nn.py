@@ -40,8 +40,7 @@ class SAGEConv(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
         g = graph_of(edge_index, x.size(0))
-        agg = Fn.aggregate(x, g, mean=True)
-        return Fn.dual_linear(agg, self.lin_l.weight, x, self.lin_r.weight, self.lin_l.bias)
+        return Fn.sage_conv(x, g, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, mean=True)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, aggr=mean"
@@ -60,8 +59,7 @@ class GraphConv(nn.Module):
 
     def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
         g = graph_of(edge_index, x.size(0))
-        agg = Fn.aggregate(x, g, mean=False)
-        return Fn.dual_linear(agg, self.lin_rel.weight, x, self.lin_root.weight, self.lin_rel.bias)
+        return Fn.sage_conv(x, g, self.lin_rel.weight, self.lin_rel.bias, self.lin_root.weight, mean=False)
 
 
 class GCNConv(nn.Module):
