@@ -138,22 +138,23 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     }
 }
 
-// One workgroup = 16 columns x 16 slices of the partial list; slices are combined through LDS
+// One workgroup = 16 columns x 64 slices of the partial list; slices are combined through LDS
 // in a fixed order, so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks,
+constexpr int FIN_SL = 64;
+__global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks,
                                                            int64_t rows_per_block, int64_t N, int H, int Hp,
                                                            float eps, float momentum,
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var,
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_rstd) {
-    __shared__ double sh[16][17];
+    __shared__ double sh[FIN_SL][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < H;
     double acc = 0.0;
     if (ok) {
-        for (int b = sl; b < nblocks; b += 16) {
+        for (int b = sl; b < nblocks; b += FIN_SL) {
             const int64_t r0 = (int64_t)b * rows_per_block;
             const double nb = (double)(min(N, r0 + rows_per_block) - r0);
             acc += nb * (double)partial[((int64_t)b * 2) * Hp + c];
@@ -163,12 +164,12 @@ __global__ __launch_bounds__(256) void k_ep_stats_finalize(const float* __restri
     __syncthreads();
     double msum = 0.0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) msum += sh[s][cl];
+    for (int s = 0; s < FIN_SL; ++s) msum += sh[s][cl];
     const double mean = msum / (double)N;
     __syncthreads();
     acc = 0.0;
     if (ok) {
-        for (int b = sl; b < nblocks; b += 16) {
+        for (int b = sl; b < nblocks; b += FIN_SL) {
             const int64_t r0 = (int64_t)b * rows_per_block;
             const double nb = (double)(min(N, r0 + rows_per_block) - r0);
             const double dm = (double)partial[((int64_t)b * 2) * Hp + c] - mean;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void k_ep_stats_finalize(const float* __restri
     if (sl != 0 || !ok) return;
     double m2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) m2 += sh[s][cl];
+    for (int s = 0; s < FIN_SL; ++s) m2 += sh[s][cl];
     if (m2 < 0.0) m2 = 0.0;
     const double var = m2 / (double)N;
     save_mean[c] = (float)mean;
@@ -271,16 +272,16 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
     }
 }
 
-__global__ __launch_bounds__(256) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
+__global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
                                                          int Hp, float* __restrict__ sums,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sh1[16][17];
-    __shared__ double sh2[16][17];
+    __shared__ double sh1[FIN_SL][17];
+    __shared__ double sh2[FIN_SL][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < H) {
-        for (int b = sl; b < nblocks; b += 16) {
+        for (int b = sl; b < nblocks; b += FIN_SL) {
             a1 += (double)partial[((int64_t)b * 2 + 0) * Hp + c];
             a2 += (double)partial[((int64_t)b * 2 + 1) * Hp + c];
         }
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void k_ep_bwd_finalize(const float* __restrict
     if (sl != 0 || c >= Hp) return;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { s1 += sh1[s][cl]; s2 += sh2[s][cl]; }
+    for (int s = 0; s < FIN_SL; ++s) { s1 += sh1[s][cl]; s2 += sh2[s][cl]; }
     sums[c] = (float)s1;
     sums[Hp + c] = (float)s2;
     if (c < H) {
@@ -342,9 +343,9 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.relu = relu; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
     a.mask = mask; a.seed = seed; a.offset = offset;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
-    // row ranges: aim at ~64 iterations per thread, at most 1024 workgroups
-    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 64);
-    if (nb > 1024) nb = 1024;
+    // row ranges: enough workgroups to fill the chip (8 per CU), at least 8 rows per thread
+    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 8);
+    if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     a.rows_per_block = hgv_cdiv(N, nb);
     *nblocks = (int)hgv_cdiv(N, a.rows_per_block);
@@ -377,7 +378,7 @@ extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(out, ldo, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
     else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 15) / 16), dim3(256), 0, stream, partial, nb, a.rows_per_block, N,
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, N,
                        H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd);
     NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
     if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
@@ -419,7 +420,7 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(dy, lddy, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_stats<true>, dim3(nb), dim3(256), 0, stream, a, b, partial);
     else hipLaunchKernelGGL(k_ep_bwd_stats<false>, dim3(nb), dim3(256), 0, stream, a, b, partial);
-    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(256), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_apply<true>, dim3(nb), dim3(256), 0, stream, a, b);
     else hipLaunchKernelGGL(k_ep_bwd_apply<false>, dim3(nb), dim3(256), 0, stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd");
