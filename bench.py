@@ -106,13 +106,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="protein256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured HIP graph (per-launch event timing is then taken "
+                         "from a short eager pass after the timed region)")
     ap.add_argument("--cpu-sample-graphs", type=int, default=4)
     args = ap.parse_args()
 
     import torch.distributed as dist
     import hgvae_amd
     from hgvae_amd import functional as Fn
-    from hgvae_amd.distributed import FlatGradBucket, init_from_env
+    from hgvae_amd.distributed import FlatGradBucket, barrier, init_from_env
     from hgvae_amd.graph import graph_of
     from hgvae_amd.vae import SkipconVAE, train_step_loss
 
@@ -122,12 +125,16 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
+    def note(msg):
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"building workload {args.workload} on cuda:{local_rank}")
     batch, dims = build_workload(args.workload, rank, device)
     n_nodes, n_edges, n_graphs = batch.x.size(0), batch.edge_index.size(1), batch.num_graphs
     torch.manual_seed(0)
     hgvae_amd.manual_seed(1234 + rank)
     model = SkipconVAE(*dims).to(device).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=args.graph)
     bucket = FlatGradBucket(model.parameters())
     graph = graph_of(batch.edge_index, n_nodes)  # CSR of the batch: built once, reused by every step
     graph.check()
@@ -140,21 +147,32 @@ def main():
         opt.step()
         return loss
 
+    note("workload and CSR ready; warm-up")
+    probe = Fn.LaunchProbe()
+    if args.graph:
+        from hgvae_amd.graphed import GraphedTrainStep
+        eager_step = step
+        step = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, bucket=bucket,
+                                seed=1234 + rank, warmup=max(args.warmup, 1))
     for _ in range(args.warmup):
         step()
-    probe = Fn.LaunchProbe()
-    Fn.set_probe(probe)
+    note("timed region")
+    if not args.graph:
+        Fn.set_probe(probe)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     host_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (diagnostic only)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     elapsed = time.perf_counter() - t0
+    if args.graph:   # kernels inside a replayed graph cannot be bracketed by events: time them eagerly now
+        Fn.set_probe(probe)
+        for _ in range(3):
+            eager_step()
+        torch.cuda.synchronize()
     Fn.set_probe(None)
 
     stats = torch.tensor([elapsed, float(n_graphs), float(n_edges), float(n_nodes)], dtype=torch.float64, device=device)
@@ -166,22 +184,32 @@ def main():
     tot_graphs, tot_edges, tot_nodes = stats[1].item(), stats[2].item(), stats[3].item()
 
     if rank == 0:
-        # roofline of the dominant kernel: unweighted forward aggregation at the hidden width
+        # roofline of the dominant kernel k_aggregate<4,false> (unweighted aggregation, every width it ran at):
+        # sum of algorithmic bytes / sum of launch durations, so that avg_launch_us is directly comparable with
+        # the rocprofv3 --kernel-trace --stats average for that kernel name
         recs = probe.durations_ms()
         h = dims[1]
-        dom = [ms for (n, f, e, w, ms) in recs if f == h and not w]
-        allb = sum(agg_bytes(n, f, e) + (4 * e if w else 0) for (n, f, e, w, ms) in recs)
-        allms = sum(ms for (*_, ms) in recs)
+        dom = [(n, f, e, ms) for (n, f, e, w, ms) in recs if not w]
+        wtd = [(n, f, e, ms) for (n, f, e, w, ms) in recs if w]
         roof = None
         if dom:
-            avg_ms = sum(dom) / len(dom)
-            achieved = agg_bytes(n_nodes, h, n_edges) / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false> (mean aggregation, F=%d)" % h,
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, h),
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": len(dom),
-                    "algorithmic_bytes_per_launch": agg_bytes(n_nodes, h, n_edges),
-                    "all_aggregations_GBps": round(allb / (allms * 1e-3) / 1e9, 1) if allms > 0 else None}
+            tot_ms = sum(ms for (*_, ms) in dom)
+            tot_b = sum(agg_bytes(n, f, e) for (n, f, e, ms) in dom)
+            achieved = tot_b / (tot_ms * 1e-3) / 1e9
+            at_h = [ms for (n, f, e, ms) in dom if f == h]
+            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false>", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": measured_traffic(args.workload, h),
+                    "avg_launch_us": round(tot_ms / len(dom) * 1e3, 2), "launches": len(dom),
+                    "algorithmic_bytes_per_launch": round(tot_b / len(dom)),
+                    "widths": sorted({f for (n, f, e, ms) in dom}),
+                    "at_hidden_width": {"F": h, "avg_launch_us": round(sum(at_h) / len(at_h) * 1e3, 2) if at_h else None,
+                                        "algorithmic_bytes": agg_bytes(n_nodes, h, n_edges),
+                                        "traffic_note": "traffic is the PMC-measured HBM bytes of one launch at this width"},
+                    "weighted_kernel": {"kernel": "k_aggregate<4,true>", "launches": len(wtd),
+                                        "avg_launch_us": round(sum(ms for (*_, ms) in wtd) / len(wtd) * 1e3, 2) if wtd else None,
+                                        "achieved": round(sum(agg_bytes(n, f, e) + 4 * e for (n, f, e, ms) in wtd)
+                                                          / (sum(ms for (*_, ms) in wtd) * 1e-3) / 1e9, 1) if wtd else None}}
         out = {
             "metric": "GVAE train graphs/sec", "value": round(tot_graphs * args.steps / elapsed, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,7 +220,8 @@ def main():
                                     "large": "one synthetic graph per GPU: 100k nodes, 2M edges, 128-d features, VAE(128,128,28)",
                                     "chig32": "32 chignolin-sized path graphs (138 nodes) per GPU, VAE(60,138,28)"}[args.workload],
                        "graphs_per_gpu": n_graphs, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
-                       "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-3"},
+                       "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-3",
+                       "launch": "hip graph replay" if args.graph else "eager"},
             "edge_messages_per_s": round(14 * tot_edges * args.steps / elapsed, 1),
             "loss": round(float(loss.item()), 6),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
@@ -204,7 +233,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 

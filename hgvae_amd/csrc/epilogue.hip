@@ -26,6 +26,7 @@ struct EpArgs {
     float p; float scale;
     const uint8_t* mask;             // [N, H] contiguous
     uint64_t seed, offset;
+    const uint64_t* offset_dev;      // optional device word added to offset (advanced once per step under graph replay)
 };
 
 template <bool VEC>
@@ -68,8 +69,9 @@ __device__ __forceinline__ float4 keep4(const EpArgs& a, int64_t row, int chunk)
         k.w = (c0 + 3 < a.H && m[3]) ? a.scale : 0.f;
     } else if (a.mode == 2) {
         const HgvPhilox ph(a.seed);
+        const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
         const uint4 r = ph((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)chunk << 8),
-                           (uint32_t)a.offset, (uint32_t)(a.offset >> 32));
+                           (uint32_t)off, (uint32_t)(off >> 32));
         k.x = hgv_u01(r.x) >= a.p ? a.scale : 0.f;
         k.y = hgv_u01(r.y) >= a.p ? a.scale : 0.f;
         k.z = hgv_u01(r.z) >= a.p ? a.scale : 0.f;
@@ -335,13 +337,13 @@ __global__ __launch_bounds__(256) void k_ep_bwd_apply(const EpArgs a, const BwdA
 bool vec4_ok(const float* p, int64_t ld, int Hp) { return p == nullptr || (hgv_aligned(p, 16) && ld % 4 == 0 && ld >= Hp); }
 
 int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
-              uint64_t seed, uint64_t offset, int* nblocks) {
+              uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int* nblocks) {
     HGV_REQUIRE(N > 0 && H > 0 && H <= 1024, HGV_EINVAL, "bn_act: need N > 0 and 0 < H <= 1024 (N=%lld H=%d)", (long long)N, H);
     HGV_REQUIRE(y && ldy >= H, HGV_EINVAL, "bn_act: bad input buffer");
     HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "bn_act: dropout p=%f outside [0,1)", p);
     a.y = y; a.ldy = ldy; a.N = N; a.H = H; a.CH = (H + 3) / 4; a.RPB = 256 / a.CH;
     a.relu = relu; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
-    a.mask = mask; a.seed = seed; a.offset = offset;
+    a.mask = mask; a.seed = seed; a.offset = offset; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
     // row ranges: enough workgroups to fill the chip (8 per CU), at least 8 rows per thread
     int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 8);
@@ -364,12 +366,13 @@ extern "C" size_t hgv_bn_act_ws(int64_t N, int H) {
 // p > 0 and no mask the keep decisions come from Philox4x32-10 keyed by (seed, offset, row,
 // chunk) and the backward pass regenerates them from the same (seed, offset).
 extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
-                              uint64_t seed, uint64_t offset, const float* gamma, const float* beta, float eps,
+                              uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma,
+                              const float* beta, float eps,
                               float* running_mean, float* running_var, float momentum, float* save_mean,
                               float* save_rstd, float* out, int64_t ldo, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
     EpArgs a; int nb;
-    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, &nb);
+    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(out && ldo >= H && save_mean && save_rstd && ws, HGV_EINVAL, "bn_act_fwd: null/short buffer");
     HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_fwd: workspace too small or misaligned");
@@ -392,7 +395,7 @@ extern "C" int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, in
                                const float* beta, float eps, const float* running_mean, const float* running_var,
                                float* out, int64_t ldo, hipStream_t stream) {
     EpArgs a; int nb;
-    int rc = make_args(a, y, ldy, N, H, relu, 0.f, nullptr, 0, 0, &nb);
+    int rc = make_args(a, y, ldy, N, H, relu, 0.f, nullptr, 0, 0, nullptr, &nb);
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(out && ldo >= H && running_mean && running_var, HGV_EINVAL, "bn_act_eval: null/short buffer");
     const int Hp = a.CH * 4;
@@ -405,11 +408,12 @@ extern "C" int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, in
 
 // Backward of the training-mode forward: dy (w.r.t. the pre-activation), dgamma, dbeta.
 extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu,
-                              float p, const uint8_t* mask, uint64_t seed, uint64_t offset, const float* gamma,
+                              float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                              const uint64_t* offset_dev, const float* gamma,
                               const float* save_mean, const float* save_rstd, float* dy, int64_t lddy,
                               float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream) {
     EpArgs a; int nb;
-    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, &nb);
+    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(g && ldg >= H && dy && lddy >= H && save_mean && save_rstd && ws, HGV_EINVAL, "bn_act_bwd: null/short buffer");
     HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd: workspace too small or misaligned");

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void k_gat_softmax_fwd(const int32_t* __restri
                                                          const float* __restrict__ a_src, int64_t lds_,
                                                          const float* __restrict__ a_dst, int64_t ldd_, float slope,
                                                          float p, float scale, const uint8_t* __restrict__ mask,
-                                                         int use_philox, uint64_t seed, uint64_t offset,
+                                                         int use_philox, uint64_t seed, uint64_t offset0,
+                                                         const uint64_t* __restrict__ offset_dev,
                                                          float* __restrict__ alpha, float* __restrict__ alpha_drop) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
     const int lr = threadIdx.x & (GL - 1);
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void k_gat_softmax_fwd(const int32_t* __restri
     for (int k = start + lr; k < end; k += GL) s += expf(leaky(a_src[(int64_t)col[k] * lds_] + ad, slope) - m);
     s = grp_sum(s) + 1e-16f;
     const HgvPhilox ph(seed);
+    const uint64_t offset = offset0 + (offset_dev ? offset_dev[0] : 0ull);
     for (int k = start + lr; k < end; k += GL) {
         const float al = expf(leaky(a_src[(int64_t)col[k] * lds_] + ad, slope) - m) / s;
         alpha[k] = al;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void k_gat_softmax_bwd(const int32_t* __restri
 extern "C" int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
                                    const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst,
                                    float slope, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                                   const uint64_t* offset_dev,
                                    float* alpha, float* alpha_drop, hipStream_t stream) {
     HGV_REQUIRE(N >= 0, HGV_EINVAL, "gat_softmax_fwd: negative N");
     if (N == 0) return HGV_OK;
@@ -135,7 +138,7 @@ extern "C" int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, co
     const float scale = 1.0f / (float)(1.0 - (double)p);
     const int64_t blocks = hgv_cdiv(N * GL, 256);
     hipLaunchKernelGGL(k_gat_softmax_fwd, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, perm, N, a_src,
-                       ld_src, a_dst, ld_dst, slope, p, scale, mask, (mask == nullptr && p > 0.f) ? 1 : 0, seed, offset,
+                       ld_src, a_dst, ld_dst, slope, p, scale, mask, (mask == nullptr && p > 0.f) ? 1 : 0, seed, offset, offset_dev,
                        alpha, alpha_drop);
     HGV_CHECK_LAUNCH("gat_softmax_fwd");
     return HGV_OK;

@@ -26,10 +26,12 @@ __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
 // eps_bar = mean_k eps_k (needed by the backward pass).
 __global__ __launch_bounds__(256) void k_reparam_fwd(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z,
                                                      int n_samples, const float* __restrict__ eps, uint64_t seed,
-                                                     uint64_t offset, float* __restrict__ z, int64_t ldz,
+                                                     uint64_t offset0, const uint64_t* __restrict__ offset_dev,
+                                                     float* __restrict__ z, int64_t ldz,
                                                      float* __restrict__ eps_bar) {
     const int64_t total = N * Z;
     const float inv_n = 1.0f / (float)n_samples;
+    const uint64_t offset = offset0 + (offset_dev ? offset_dev[0] : 0ull);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / Z;
         const int c = (int)(i - row * Z);
@@ -162,13 +164,14 @@ int grid_for(int64_t total) {
 extern "C" size_t hgv_loss_ws(void) { return RED_BLOCKS * sizeof(float); }
 
 extern "C" int hgv_reparam_fwd(const float* ml, int64_t ldm, int64_t N, int Z, int n_samples, const float* eps,
-                               uint64_t seed, uint64_t offset, float* z, int64_t ldz, float* eps_bar,
+                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* z, int64_t ldz,
+                               float* eps_bar,
                                hipStream_t stream) {
     HGV_REQUIRE(N >= 0 && Z > 0 && n_samples > 0, HGV_EINVAL, "reparam_fwd: bad sizes");
     if (N == 0) return HGV_OK;
     HGV_REQUIRE(ml && z && eps_bar && ldm >= 2 * Z && ldz >= Z, HGV_EINVAL, "reparam_fwd: null/short buffer");
     hipLaunchKernelGGL(k_reparam_fwd, dim3(grid_for(N * Z)), dim3(256), 0, stream, ml, ldm, N, Z, n_samples, eps, seed,
-                       offset, z, ldz, eps_bar);
+                       offset, offset_dev, z, ldz, eps_bar);
     HGV_CHECK_LAUNCH("reparam_fwd");
     return HGV_OK;
 }

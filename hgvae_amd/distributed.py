@@ -26,11 +26,23 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+            # HGVAE_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
+            backend = os.environ.get("HGVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def barrier(group=None) -> None:
+    """dist.barrier pinned to this rank's GPU under the RCCL backend (no-op for one rank)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier(group=group)
 
 
 class FlatGradBucket:

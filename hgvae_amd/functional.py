@@ -312,7 +312,7 @@ def dual_linear(xa, wa, xb=None, wb=None, bias=None):
 # --------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, eps, momentum):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum):
         _lib.require_cuda(y)
         y = rowmajor(y)
         n, h = y.shape
@@ -323,18 +323,18 @@ class _BnAct(torch.autograd.Function):
         out = new_padded(n, h, y.device, zero_pad=False)
         save_mean = torch.empty(h, dtype=torch.float32, device=y.device)
         save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
-        _lib.call("hgv_bn_act_fwd", y.data_ptr(), ld_of(y), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset,
+        _lib.call("hgv_bn_act_fwd", y.data_ptr(), ld_of(y), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
                   _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
                   float(momentum), save_mean.data_ptr(), save_rstd.data_ptr(), out.data_ptr(), ld_of(out),
                   ws.data_ptr(), ws.numel(), _lib.stream())
-        ctx.cfg = (relu, p, seed, offset)
+        ctx.cfg = (relu, p, seed, offset, ctr)
         ctx.save_for_backward(y, gamma, save_mean, save_rstd, mask)
         return out
 
     @staticmethod
     def backward(ctx, g):
         y, gamma, save_mean, save_rstd, mask = ctx.saved_tensors
-        relu, p, seed, offset = ctx.cfg
+        relu, p, seed, offset, ctr = ctx.cfg
         g = rowmajor(g)
         n, h = y.shape
         lib = _lib.load()
@@ -343,12 +343,12 @@ class _BnAct(torch.autograd.Function):
         dgamma = torch.empty(h, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(h, dtype=torch.float32, device=y.device)
         _lib.call("hgv_bn_act_bwd", g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), n, h, int(relu), float(p),
-                  _lib.ptr(mask), seed, offset, _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
+                  _lib.ptr(mask), seed, offset, ctr, _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
                   dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
                   _lib.stream())
         need = ctx.needs_input_grad
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool) -> torch.Tensor:
@@ -361,12 +361,12 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
                   _lib.ptr(bn.bias), float(bn.eps), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                   out.data_ptr(), ld_of(out), _lib.stream())
         return out
-    mask, seed, offset = None, 0, 0
+    mask, seed, offset, ctr = None, 0, 0, None
     if p > 0.0:
-        mask, seed, offset = current_noise().dropout(y.shape, y.device)
+        mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
-    out = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, bn.eps,
-                       momentum)
+    out = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, ctr,
+                       bn.eps, momentum)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return out
@@ -377,12 +377,12 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
 # --------------------------------------------------------------------------------------
 class _Reparam(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ml, z_dim, n_samples, eps, seed, offset):
+    def forward(ctx, ml, z_dim, n_samples, eps, seed, offset, ctr):
         ml = rowmajor(ml)
         n = ml.size(0)
         z = new_padded(n, z_dim, ml.device)
         eps_bar = torch.empty(n, z_dim, dtype=torch.float32, device=ml.device)
-        _lib.call("hgv_reparam_fwd", ml.data_ptr(), ld_of(ml), n, z_dim, n_samples, _lib.ptr(eps), seed, offset,
+        _lib.call("hgv_reparam_fwd", ml.data_ptr(), ld_of(ml), n, z_dim, n_samples, _lib.ptr(eps), seed, offset, ctr,
                   z.data_ptr(), ld_of(z), eps_bar.data_ptr(), _lib.stream())
         ctx.z_dim = z_dim
         ctx.save_for_backward(ml, eps_bar)
@@ -395,14 +395,14 @@ class _Reparam(torch.autograd.Function):
         gml = new_padded(ml.size(0), 2 * ctx.z_dim, ml.device)
         _lib.call("hgv_reparam_bwd", gz.data_ptr(), ld_of(gz), ml.data_ptr(), ld_of(ml), ml.size(0), ctx.z_dim,
                   eps_bar.data_ptr(), gml.data_ptr(), ld_of(gml), _lib.stream())
-        return gml, None, None, None, None, None
+        return gml, None, None, None, None, None, None
 
 
 def reparameterize(ml: torch.Tensor, z_dim: int, n_samples: int) -> torch.Tensor:
     """z = mean over n_samples of (mean + exp(log_std) * eps_k); ml = [mean | log_std]."""
     _lib.require_cuda(ml)
-    eps, seed, offset = current_noise().normal((n_samples, ml.size(0), z_dim), ml.device)
-    return _Reparam.apply(ml, z_dim, n_samples, eps, seed, offset)
+    eps, seed, offset, ctr = current_noise().normal((n_samples, ml.size(0), z_dim), ml.device)
+    return _Reparam.apply(ml, z_dim, n_samples, eps, seed, offset, ctr)
 
 
 class _KL(torch.autograd.Function):
@@ -470,7 +470,7 @@ class _GatAggregate(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xw, a_src, a_dst, lg: Graph, slope, p, mask, seed, offset):
+    def forward(ctx, xw, a_src, a_dst, lg: Graph, slope, p, mask, seed, offset, ctr):
         _lib.require_cuda(xw, a_src, a_dst)
         xw = as_padded(xw)
         a_src, a_dst = a_src.contiguous(), a_dst.contiguous()
@@ -479,7 +479,7 @@ class _GatAggregate(torch.autograd.Function):
         alpha = torch.empty(e, dtype=torch.float32, device=xw.device)
         alpha_drop = torch.empty(e, dtype=torch.float32, device=xw.device)
         _lib.call("hgv_gat_softmax_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n,
-                  a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(slope), float(p), _lib.ptr(mask), seed, offset,
+                  a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(slope), float(p), _lib.ptr(mask), seed, offset, ctr,
                   alpha.data_ptr(), alpha_drop.data_ptr(), _lib.stream())
         out = new_padded(n, xw.size(1), xw.device, zero_pad=False)
         _agg_launch(csr, n, xw, xw.size(1), 0, None, alpha_drop, None, None, out)
@@ -509,18 +509,18 @@ class _GatAggregate(torch.autograd.Function):
         ones = torch.ones(n, 1, dtype=torch.float32, device=dev)
         da_src = torch.empty(n, 1, dtype=torch.float32, device=dev)
         _agg_launch(csr_t, n, ones, 1, 0, None, dl.index_select(0, t2f), None, None, da_src)
-        return gxw, da_src.view(n), da_dst, None, None, None, None, None, None
+        return gxw, da_src.view(n), da_dst, None, None, None, None, None, None, None
 
 
 def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, training: bool):
-    mask, seed, offset = None, 0, 0
+    mask, seed, offset, ctr = None, 0, 0, None
     if training and p > 0.0:
-        mask, seed, offset = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
+        mask, seed, offset, ctr = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
         if mask is not None:
             mask = mask.view(-1)
     else:
         p = 0.0
-    return _GatAggregate.apply(xw, a_src, a_dst, loop_graph, slope, p, mask, seed, offset)
+    return _GatAggregate.apply(xw, a_src, a_dst, loop_graph, slope, p, mask, seed, offset, ctr)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,77 @@
+"""Whole-train-step HIP graph: capture once, replay per step.
+
+One reference train step (gvae/gvae_skipcon.py:163-185) on a fixed batch is ~450 kernel
+launches; at the reference's own batch sizes (a few thousand nodes) the GPU work per launch is
+a few microseconds and the host launch path dominates.  ``GraphedTrainStep`` records
+``zero grads -> forward -> second encode -> loss -> backward (-> optimizer step)`` into a HIP
+graph on a side stream and replays it; dropout masks and normal draws stay fresh on every replay
+because the kernels add a device-side step counter to their Philox offsets.
+
+The pooling variants synchronise with the host (data-dependent output sizes) and cannot be
+captured; they keep running eagerly.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from .distributed import FlatGradBucket
+from .graph import graph_of
+from .noise import PhiloxNoise, use_noise
+from .vae import train_step_loss
+
+
+class GraphedTrainStep:
+    """Captured train step on a fixed batch.
+
+    ``optimizer`` is stepped inside the graph when it was built with ``capturable=True`` and the
+    job is single-process; otherwise (and always for world size > 1, where the gradient
+    all-reduce sits between backward and the update) it is stepped eagerly after the replay.
+    """
+
+    def __init__(self, model: torch.nn.Module, optimizer: torch.optim.Optimizer, x: torch.Tensor,
+                 edge_index: torch.Tensor, batch: Optional[torch.Tensor] = None, lambda_kl: float = 1.0,
+                 loss_fn: Callable = train_step_loss, bucket: Optional[FlatGradBucket] = None, seed: int = 0,
+                 warmup: int = 3):
+        self.model, self.optimizer = model, optimizer
+        self.x, self.edge_index, self.batch, self.lambda_kl, self.loss_fn = x, edge_index, batch, lambda_kl, loss_fn
+        self.bucket = bucket if bucket is not None else FlatGradBucket(model.parameters())
+        dev = x.device
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.noise = PhiloxNoise(seed, device_counter=self.counter)
+        graph_of(edge_index, x.size(0))  # CSR built outside the capture
+        capturable = all(g.get("capturable", False) for g in optimizer.param_groups)
+        self.optimizer_in_graph = capturable and self.bucket.world == 1
+        self.loss = None
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):        # allocates workspaces, packs, optimizer state outside the capture
+                self._body(step_optimizer=True, reduce=True)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss = self._body(step_optimizer=self.optimizer_in_graph, reduce=False)
+        torch.cuda.synchronize(dev)
+
+    def _body(self, step_optimizer: bool, reduce: bool):
+        self.noise.advance()
+        self.bucket.zero()
+        with use_noise(self.noise):
+            loss = self.loss_fn(self.model, self.x, self.edge_index, self.batch, self.lambda_kl)
+        loss.backward()
+        if reduce:
+            self.bucket.all_reduce_mean()
+        if step_optimizer:
+            self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self) -> torch.Tensor:
+        """Run one step; returns the (device-resident, overwritten on the next call) loss."""
+        self.graph.replay()
+        if not self.optimizer_in_graph:
+            self.bucket.all_reduce_mean()
+            self.optimizer.step()
+        return self.loss

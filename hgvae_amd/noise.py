@@ -16,21 +16,40 @@ from typing import List, Optional
 import torch
 
 
+STEP_STRIDE = 1 << 40   # device-counter increment per step; host offsets stay below it
+
+
 class PhiloxNoise:
-    def __init__(self, seed: Optional[int] = None):
+    """Counter-based noise: every stochastic layer call gets its own ``offset``.
+
+    ``device_counter`` (optional, int64[1] on the GPU) is added to the offset inside the kernels.
+    A captured graph replays fixed host offsets, so the training step advances this counter on the
+    device (``advance()``) to draw fresh noise on every replay.
+    """
+
+    def __init__(self, seed: Optional[int] = None, device_counter: Optional[torch.Tensor] = None):
         self.seed = int(torch.initial_seed() if seed is None else seed) & ((1 << 64) - 1)
         self.offset = 0
+        self.device_counter = device_counter
 
     def _next(self) -> int:
         # 2**20 counter values per call keep the (offset + k) sub-streams of one call disjoint
-        self.offset += 1 << 20
+        self.offset = (self.offset + (1 << 20)) % STEP_STRIDE
         return self.offset
 
+    def _ctr(self):
+        return None if self.device_counter is None else self.device_counter.data_ptr()
+
     def dropout(self, shape, device):
-        return None, self.seed, self._next()
+        return None, self.seed, self._next(), self._ctr()
 
     def normal(self, shape, device):
-        return None, self.seed, self._next()
+        return None, self.seed, self._next(), self._ctr()
+
+    def advance(self) -> None:
+        """Move the device counter to the next step (an in-place device op: capturable)."""
+        if self.device_counter is not None:
+            self.device_counter.add_(STEP_STRIDE)
 
 
 class NoiseTape:
@@ -50,10 +69,10 @@ class NoiseTape:
         return t.to(device)
 
     def dropout(self, shape, device):
-        return self._pop(shape, device).to(torch.uint8).contiguous(), 0, 0
+        return self._pop(shape, device).to(torch.uint8).contiguous(), 0, 0, None
 
     def normal(self, shape, device):
-        return self._pop(shape, device).to(torch.float32).contiguous(), 0, 0
+        return self._pop(shape, device).to(torch.float32).contiguous(), 0, 0, None
 
 
 _default = PhiloxNoise(seed=0x5EED)

@@ -79,18 +79,19 @@ int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, c
 /* ---- fused (ReLU) -> Dropout -> BatchNorm1d over nodes: gvae/gvae_skipcon.py:105-107,
  *      110-112,115-117,124,130,136 ----------------------------------------------------------
  * y is the pre-activation [N, H].  Dropout keep mask: explicit uint8 [N,H] (contiguous), or
- * Philox4x32-10 keyed by (seed, offset) when mask is null and p > 0.  Biased batch variance
+ * Philox4x32-10 keyed by (seed, offset) when mask is null and p > 0; offset_dev (nullable) is a device
+ * word added to offset, so a captured graph can draw fresh noise on every replay.  Biased batch variance
  * for normalisation, unbiased for the running update (torch.nn.BatchNorm1d semantics). */
 size_t hgv_bn_act_ws(int64_t N, int H);
 int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
-                   uint64_t seed, uint64_t offset, const float* gamma, const float* beta, float eps,
+                   uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
                    float* running_mean, float* running_var, float momentum, float* save_mean, float* save_rstd,
                    float* out, int64_t ldo, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, int relu, const float* gamma, const float* beta,
                     float eps, const float* running_mean, const float* running_var, float* out, int64_t ldo,
                     hgv_stream_t stream);
 int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
-                   const uint8_t* mask, uint64_t seed, uint64_t offset, const float* gamma, const float* save_mean,
+                   const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* save_mean,
                    const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* ws,
                    size_t ws_bytes, hgv_stream_t stream);
 
@@ -100,7 +101,8 @@ int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int
  * eps_bar [N, Z] (mean of the draws) is an output kept for the backward pass. */
 size_t hgv_loss_ws(void);
 int hgv_reparam_fwd(const float* ml, int64_t ldm, int64_t N, int Z, int n_samples, const float* eps, uint64_t seed,
-                    uint64_t offset, float* z, int64_t ldz, float* eps_bar, hgv_stream_t stream);
+                    uint64_t offset, const uint64_t* offset_dev, float* z, int64_t ldz, float* eps_bar,
+                    hgv_stream_t stream);
 int hgv_reparam_bwd(const float* gz, int64_t ldgz, const float* ml, int64_t ldm, int64_t N, int Z,
                     const float* eps_bar, float* gml, int64_t ldg, hgv_stream_t stream);
 int hgv_kl_fwd(const float* ml, int64_t ldm, int64_t N, int Z, float* out, void* ws, size_t ws_bytes,
@@ -126,7 +128,8 @@ int hgv_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws,
  * element stride (ld_src / ld_dst) so one head of an [N, heads] table can be passed. */
 int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
                         const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
-                        const uint8_t* mask, uint64_t seed, uint64_t offset, float* alpha, float* alpha_drop,
+                        const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* alpha,
+                        float* alpha_drop,
                         hgv_stream_t stream);
 /* Backward: dad[k] = <g[i,:], xw[col[k],:]>; dl[k] = gradient w.r.t. the pre-leaky logit of edge k;
  * da_dst[i] = sum_k dl[k].  (da_src is the sum of dl over each source's out-edges: hgv_agg_fwd on

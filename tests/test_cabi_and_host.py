@@ -111,7 +111,7 @@ def test_read_pyg_pt_tensors_reads_raw_storages_without_unpickling(tmp_path):
 def test_noise_tape_order_and_shape_checks():
     from hgvae_amd.noise import NoiseTape, PhiloxNoise
     t = NoiseTape([torch.ones(3, 2), torch.zeros(4, 3, 2)])
-    m, _, _ = t.dropout((3, 2), torch.device("cpu"))
+    m, _, _, _ = t.dropout((3, 2), torch.device("cpu"))
     assert m.dtype == torch.uint8 and m.sum() == 6
     with pytest.raises(RuntimeError):
         t.dropout((9, 9), torch.device("cpu"))
