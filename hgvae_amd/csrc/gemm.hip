@@ -5,9 +5,11 @@
 //   forward / grad-input :  C[M,N] = A1[M,K1] W1^T + A2[M,K2] W2^T (+ bias)     (k_gemm_nt)
 //                           i.e. the K-concatenated [agg | x] x [W_l | W_r]^T of one SAGE layer,
 //                           or [h | skip] x W^T of a decoder level, without materialising the concat.
-//                           Weights are first PACKED (k_pack_weight) into a zero-padded, k-contiguous
-//                           [ceil16(N)][ceil32(K)] image - from W (forward) or from W^T (grad-input) -
-//                           so the GEMM stages them with plain 16-byte loads and needs no masks.
+//                           Weights are first PACKED (k_pack_weight) into a zero-padded image ordered as the
+//                           MFMA consumes it - from W (forward) or from W^T (grad-input).  When the image
+//                           fits in LDS (<= 160 KB, true for every layer of the 138-wide model) it stays
+//                           resident there and waves stream rows of A without barriers (k_gemm_nt_res);
+//                           larger weights are staged per 32-wide k chunk (k_gemm_nt).
 //   grad-weight          :  GW[N,K] = G[M,N]^T A[M,K], bias grad = column sums of G  (k_gemm_tn)
 //                           reduction over the M rows split over workgroups, partials combined by a
 //                           second kernel in a fixed order (no atomics -> reproducible).
@@ -31,35 +33,231 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // ------------------------------------------------------------------------------------------
 // weight packing
 // ------------------------------------------------------------------------------------------
+// Packed image of a weight: [Gp][R][4] floats, where group g holds k = 4g..4g+3, R = 16 * (n tiles)
+// rows and Gp = ceil(K/32)*8 groups; element (n,k) = W[n*sn + k*sk] inside [N][K] and zero outside.
+// An MFMA lane (i, kq) reads the 16 bytes of (group, row i) as one operand quad, so a wave's
+// ds_read_b128 touches 16 consecutive 16-byte slots per k group: conflict-free without padding.
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ W, int64_t sn, int64_t sk, int N, int K,
-                                                     float* __restrict__ out, int rows_p, int Kp) {
-    const int64_t total = (int64_t)rows_p * Kp;
+                                                     float* __restrict__ out, int R, int Gp) {
+    const int64_t total = (int64_t)Gp * R * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(e / Kp), k = (int)(e - (int64_t)n * Kp);
+        const int gidx = (int)(e / (R * 4)), rem = (int)(e - (int64_t)gidx * R * 4);
+        const int n = rem >> 2, k = 4 * gidx + (rem & 3);
         out[e] = (n < N && k < K) ? W[(int64_t)n * sn + (int64_t)k * sk] : 0.f;
     }
 }
 
-// rows [row_offset, row_offset + N) of a packed image whose other rows the caller keeps zero
+// rows [row_offset, row_offset + N) of a packed image with R rows whose other rows the caller keeps zero
 __global__ __launch_bounds__(256) void k_pack_weight_rows(const float* __restrict__ W, int64_t sn, int64_t sk, int N,
-                                                          int K, float* __restrict__ out, int row_offset, int Kp) {
-    const int64_t total = (int64_t)N * Kp;
+                                                          int K, float* __restrict__ out, int row_offset, int R, int Gp) {
+    const int64_t total = (int64_t)Gp * N * 4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(e / Kp), k = (int)(e - (int64_t)n * Kp);
-        out[(int64_t)(row_offset + n) * Kp + k] = k < K ? W[(int64_t)n * sn + (int64_t)k * sk] : 0.f;
+        const int gidx = (int)(e / (N * 4)), rem = (int)(e - (int64_t)gidx * N * 4);
+        const int n = rem >> 2, k = 4 * gidx + (rem & 3);
+        out[((int64_t)gidx * R + row_offset + n) * 4 + (rem & 3)] = k < K ? W[(int64_t)n * sn + (int64_t)k * sk] : 0.f;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// NT kernel on packed weights
+// NT kernel, weights resident in LDS
 // ------------------------------------------------------------------------------------------
-constexpr int G_BM = 128;   // rows per workgroup (32 per wave)
+// The whole packed weight (both sources) is copied into LDS once per workgroup; after that single
+// barrier every wave streams 16-row tiles of A on its own: A operand quads come straight from
+// global memory into registers (a ring of RING loads in flight per wave, running ahead across tile
+// boundaries), weight quads from LDS.  No barriers and no LDS traffic for A in the main loop.
+// The MFMA operands are swapped (weights as the row operand), so a lane ends up with 4 consecutive
+// output columns of one row and stores them as one 16-byte piece.
+struct ResSrc {
+    const float* A; int64_t lda; int G;    // G = ceil(K/4) k groups
+    const float* Wp;                       // packed image (R = NT*16 rows)
+};
+struct ResArgs {
+    ResSrc s[2]; int nsrc;
+    const float* bias;
+    float* C; int64_t ldc;
+    int64_t M; int N; int64_t ntiles;
+};
+
+__device__ __forceinline__ int res_quads(int G) {   // MFMA quads (4 k groups each) needed for G groups
+    const int rem = G & 7;
+    return 2 * (G >> 3) + (rem > 4 ? 2 : (rem > 0 ? 1 : 0));
+}
+// k group handled by lanes kq of quad q: full blocks of 8 groups are split so that a lane's two
+// consecutive quads read adjacent 16-byte pieces (a wave then covers 128 contiguous bytes per row);
+// a tail of <= 4 groups is one plain quad.
+__device__ __forceinline__ int res_group(int G, int q, int kq) {
+    const int P = G >> 3, rem = G & 7;
+    return (q < 2 * P || rem > 4) ? 8 * (q >> 1) + 2 * kq + (q & 1) : 8 * P + kq;
+}
+
+// Instruction order of one quad step, imposed on the scheduler: the LDS reads of the first two
+// pairs of n tiles, then per pair its MFMAs followed by the reads of the pair two ahead, so that
+// no MFMA waits for a read issued right before it.
+template <int NT, int RT, int NTI>
+struct ResSched {
+    static __device__ __forceinline__ void run() {
+        if constexpr (NTI < NT) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (NTI + 1 < NT ? 8 : 4) * RT, 0);
+            if constexpr (NTI + 4 < NT) __builtin_amdgcn_sched_group_barrier(0x100, NTI + 5 < NT ? 2 : 1, 0);
+            ResSched<NT, RT, NTI + 2>::run();
+        }
+    }
+};
+
+template <int NT, int RT, int RING>
+__global__ __launch_bounds__(1024) void k_gemm_nt_res(const ResArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float Wl[];   // [G1 + G2][R][4], bias[R], step table[Qp][4]
+    constexpr int R = NT * 16;
+    const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(t >> 6), wpb = blockDim.x >> 6;
+    const float* A1 = g.s[0].A; const int64_t lda1 = g.s[0].lda; const int G1 = g.s[0].G;
+    const float* A2 = g.nsrc > 1 ? g.s[1].A : g.s[0].A;
+    const int64_t lda2 = g.nsrc > 1 ? g.s[1].lda : g.s[0].lda;
+    const int G2 = g.nsrc > 1 ? g.s[1].G : 0;
+    const int nq1 = res_quads(G1), Q = nq1 + res_quads(G2);
+    const int Qp = (Q + RING - 1) / RING * RING;     // steps per tile, padded to whole ring rounds
+    float* bias_s = Wl + (int64_t)(G1 + G2) * R * 4;
+    int2* tab = reinterpret_cast<int2*>(bias_s + R);
+    {
+        const int n1 = G1 * R, n2 = G2 * R;     // 16-byte pieces
+        f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+        const f32x4* w1 = reinterpret_cast<const f32x4*>(g.s[0].Wp);
+        for (int e = t; e < n1; e += blockDim.x) dst[e] = w1[e];
+        if (n2 > 0) {
+            const f32x4* w2 = reinterpret_cast<const f32x4*>(g.s[1].Wp);
+            for (int e = t; e < n2; e += blockDim.x) dst[n1 + e] = w2[e];
+        }
+        for (int e = t; e < R; e += blockDim.x) bias_s[e] = (g.bias && e < g.N) ? g.bias[e] : 0.f;
+        // Step table: for step fq of a tile and lane group kq, .x = byte offset of the A quad in its
+        // row (bit 31 set: the quad is padding and counts as zero), .y = byte offset of the weight
+        // group in LDS.  Padding quads point at valid memory (the last group) so loads stay in bounds.
+        for (int e = t; e < Qp * 4; e += blockDim.x) {
+            const int fq = min(e >> 2, Q - 1), k = e & 3;
+            const bool second = fq >= nq1;
+            const int G = second ? G2 : G1;
+            const int gi = res_group(G, second ? fq - nq1 : fq, k);
+            const int gc = min(gi, G - 1);
+            const bool keep = gi < G && (e >> 2) < Q;
+            tab[e] = make_int2((gc * 16) | (keep ? 0 : (int)0x80000000), ((second ? G1 : 0) + gc) * R * 16);
+        }
+    }
+    __syncthreads();
+
+    // tiles are dealt so that the waves holding one tile more than the others spread over all workgroups
+    const int64_t gw = (int64_t)wib * gridDim.x + blockIdx.x, nw = (int64_t)wpb * gridDim.x;
+    const int64_t my_tiles = gw < g.ntiles ? (g.ntiles - gw + nw - 1) / nw : 0;
+
+    f32x4 acc[RT][NT];
+    auto init_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&bias_s[16 * nt + 4 * kq]);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = b;
+        }
+    };
+    auto compute = [&](const f32x4 (&a_in)[RT], const int2 e) __attribute__((always_inline)) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wl) + e.y) + i;
+        // weight quads are read one pair of n tiles ahead of the MFMAs that use them
+        f32x4 b0 = wp[0], b1 = wp[NT > 1 ? 16 : 0];
+        f32x4 a[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[rt] = e.x >= 0 ? a_in[rt] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; nt += 2) {
+            f32x4 n0 = b0, n1 = b1;
+            if (nt + 2 < NT) n0 = wp[16 * (nt + 2)];
+            if (nt + 3 < NT) n1 = wp[16 * (nt + 3)];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    acc[rt][nt] = MFMA16(b0[m], a[rt][m], acc[rt][nt]);
+                    if (nt + 1 < NT) acc[rt][nt + 1] = MFMA16(b1[m], a[rt][m], acc[rt][nt + 1]);
+                }
+            }
+            b0 = n0; b1 = n1;
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, NT < 4 ? NT : 4, 0);
+        ResSched<NT, RT, 0>::run();
+    };
+    // D layout with the weights as the row operand: lane (i, kq) register r = C[row i][16 nt + 4 kq + r]
+    auto store_tile = [&](int64_t tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = tile * (16 * RT) + 16 * rt + i;
+            if (row < g.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = 16 * nt + 4 * kq;
+                    if (col < g.ldc) *reinterpret_cast<f32x4*>(g.C + row * g.ldc + col) = acc[rt][nt];
+                }
+            }
+        }
+    };
+
+    // Load cursor: runs RING steps ahead of the MFMAs, across tile boundaries.  Every ring slot
+    // issues exactly one load group per step (past the end: a repeat of the last one), so the number
+    // of loads in flight is the same on every path and each wait is a counted one.
+    // Rows past M reuse row M-1 (never stored).
+    int64_t ltile = gw, lidx = 0; int lq = 0;
+    const char* lp1[RT]; const char* lp2[RT];
+    auto row_pointers = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int64_t row = min(ltile * (16 * RT) + 16 * rt + i, g.M - 1);
+            lp1[rt] = reinterpret_cast<const char*>(A1 + row * lda1);
+            lp2[rt] = reinterpret_cast<const char*>(A2 + row * lda2);
+        }
+    };
+    f32x4 ring[RING][RT];
+    int2 ring_e[RING];
+    int2 e_next = make_int2(0, 0);
+    auto issue = [&](int d) __attribute__((always_inline)) {
+        const int2 e = e_next;
+        const bool second = min(lq, Q - 1) >= nq1;
+        ring_e[d] = e;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+            ring[d][rt] = *reinterpret_cast<const f32x4*>((second ? lp2[rt] : lp1[rt]) + (e.x & 0x7fffffff));
+        if (++lq == Qp) {
+            if (lidx + 1 < my_tiles) { lq = 0; ++lidx; ltile += nw; row_pointers(); } else lq = Qp - 1;
+        }
+        e_next = tab[lq * 4 + kq];
+    };
+    if (my_tiles > 0) {
+        row_pointers();
+        e_next = tab[kq];
+#pragma unroll
+        for (int d = 0; d < RING; ++d) issue(d);
+    }
+    int64_t ctile = gw;
+    for (int64_t ti = 0; ti < my_tiles; ++ti, ctile += nw) {
+        init_acc();
+        for (int q0 = 0; q0 < Qp; q0 += RING) {
+#pragma unroll
+            for (int d = 0; d < RING; ++d) {
+                f32x4 a[RT];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) a[rt] = ring[d][rt];
+                const int2 e = ring_e[d];
+                issue(d);
+                compute(a, e);
+            }
+        }
+        store_tile(ctile);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// NT kernel, weights staged per 32-wide k chunk (for weights too large to keep in LDS)
+// ------------------------------------------------------------------------------------------
 constexpr int G_KC = 32;    // k chunk staged in LDS
-constexpr int G_LD = 36;    // LDS row stride in floats (16-byte aligned, spreads ds_read_b128 over banks)
+constexpr int G_LD = 36;    // LDS row stride of the A tile in floats (16-byte aligned, spreads ds_read_b128 over banks)
 
 struct GemmSrc {
     const float* A; int64_t lda; int K;
-    const float* Wp; int Kp;           // packed weight [NT*16][Kp], zero outside [N][K]
+    const float* Wp;                   // packed weight image, R = NT*16 rows
 };
 struct GemmArgs {
     GemmSrc s[2]; int nsrc;
@@ -68,23 +266,27 @@ struct GemmArgs {
     int64_t M; int N;
 };
 
-template <int NT>
-__global__ __launch_bounds__(256, (NT <= 9 ? 2 : 1)) void k_gemm_nt(const GemmArgs g) {
+// RT: 16-row tiles per wave (workgroup = 4 waves = 64*RT rows); MINW: occupancy hint (waves per SIMD)
+template <int NT, int RT, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_gemm_nt(const GemmArgs g) {
+    constexpr int G_BM = 64 * RT;
+    constexpr int R = NT * 16;
     __shared__ __attribute__((aligned(16))) float As[G_BM * G_LD];
-    __shared__ __attribute__((aligned(16))) float Ws[NT * 16 * G_LD];
+    __shared__ __attribute__((aligned(16))) float Ws[R * G_KC];      // [8 groups][R][4]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int64_t row0 = (int64_t)blockIdx.x * G_BM;
 
-    f32x4 acc[2][NT];
+    f32x4 acc[RT][NT];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int WV = NT * 16 * 8;              // float4 pieces of one weight chunk
+    constexpr int WV = R * 8;                    // 16-byte pieces of one weight chunk (contiguous in the image)
     constexpr int WQ = (WV + 255) / 256;
-    f32x4 ra[4], rw[WQ];   // native vectors: arrays of HIP float4 (a struct) captured by the lambdas stay in scratch
+    constexpr int AQ = G_BM / 32;
+    f32x4 ra[AQ], rw[WQ];   // native vectors: arrays of HIP float4 (a struct) captured by the lambdas stay in scratch
     const int c4 = t & 7, r8 = t >> 3;           // this thread's 16-byte column piece / row within 32
 
     // Rows past M reuse row M-1 (their results are never stored); k pieces past K reuse the last
@@ -92,40 +294,38 @@ __global__ __launch_bounds__(256, (NT <= 9 ? 2 : 1)) void k_gemm_nt(const GemmAr
     auto load_chunk = [&](const GemmSrc s, int kc) __attribute__((always_inline)) {
         const int kb = min(kc + 4 * c4, ((s.K - 1) >> 2) << 2);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < AQ; ++q) {
             const int64_t row = min(row0 + r8 + 32 * q, g.M - 1);
             ra[q] = *reinterpret_cast<const f32x4*>(s.A + row * s.lda + kb);
         }
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(s.Wp) + (int64_t)(kc >> 2) * R;
 #pragma unroll
-        for (int q = 0; q < WQ; ++q) {
-            const int e = min(t + 256 * q, WV - 1);
-            rw[q] = *reinterpret_cast<const f32x4*>(s.Wp + (int64_t)(e >> 3) * s.Kp + kc + 4 * (e & 7));
-        }
+        for (int q = 0; q < WQ; ++q) rw[q] = wsrc[min(t + 256 * q, WV - 1)];
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&As[(r8 + 32 * q) * G_LD + 4 * c4]) = ra[q];
+        for (int q = 0; q < AQ; ++q) *reinterpret_cast<f32x4*>(&As[(r8 + 32 * q) * G_LD + 4 * c4]) = ra[q];
 #pragma unroll
         for (int q = 0; q < WQ; ++q) {
             const int e = t + 256 * q;
-            if (e < WV) *reinterpret_cast<f32x4*>(&Ws[(e >> 3) * G_LD + 4 * (e & 7)]) = rw[q];
+            if (e < WV) *reinterpret_cast<f32x4*>(&Ws[4 * e]) = rw[q];
         }
     };
     auto compute = [&](int kvalid) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (16 * u < kvalid) {
-                f32x4 a[2];
+                f32x4 a[RT];
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-                    a[rt] = *reinterpret_cast<const f32x4*>(&As[(32 * w + 16 * rt + i) * G_LD + 16 * u + 4 * kq]);
+                for (int rt = 0; rt < RT; ++rt)
+                    a[rt] = *reinterpret_cast<const f32x4*>(&As[(16 * RT * w + 16 * rt + i) * G_LD + 16 * u + 4 * kq]);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[(16 * nt + i) * G_LD + 16 * u + 4 * kq]);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&Ws[((4 * u + kq) * R + 16 * nt + i) * 4]);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        acc[0][nt] = MFMA16(a[0][m], b[m], acc[0][nt]);
-                        acc[1][nt] = MFMA16(a[1][m], b[m], acc[1][nt]);
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = MFMA16(a[rt][m], b[m], acc[rt][nt]);
                     }
                 }
             }
@@ -156,10 +356,10 @@ __global__ __launch_bounds__(256, (NT <= 9 ? 2 : 1)) void k_gemm_nt(const GemmAr
         const int col = 16 * nt + i;
         const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 32 * w + 16 * rt + 4 * kq + r;
+                const int64_t row = row0 + 16 * RT * w + 16 * rt + 4 * kq + r;
                 if (row < g.M && col < g.ldc) g.C[row * g.ldc + col] = col < g.N ? acc[rt][nt][r] + bv : 0.f;
             }
         }
@@ -339,7 +539,48 @@ int kp_of(int K) { return (K + 31) / 32 * 32; }
 
 template <int NT>
 void launch_nt(const GemmArgs& g, hipStream_t st) {
-    hipLaunchKernelGGL(k_gemm_nt<NT>, dim3((unsigned)hgv_cdiv(g.M, G_BM)), dim3(256), 0, st, g);
+    constexpr int W2 = NT <= 9 ? 2 : 1;
+    hipLaunchKernelGGL((k_gemm_nt<NT, 1, W2>), dim3((unsigned)hgv_cdiv(g.M, 64)), dim3(256), 0, st, g);
+}
+
+constexpr size_t RES_LDS_MAX = 160 * 1024;
+int host_quads(int G) { const int rem = G & 7; return 2 * (G >> 3) + (rem > 4 ? 2 : (rem > 0 ? 1 : 0)); }
+size_t res_lds_bytes(int R, int G1, int G2) {   // weights, bias, step table (<= 3 padding steps)
+    return ((size_t)(G1 + G2) * R * 4 + R) * sizeof(float) + (size_t)(host_quads(G1) + host_quads(G2) + 3) * 4 * 8;
+}
+
+int cu_count() {   // compute units of the current device (cached per device)
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
+template <int NT, int RING>
+int launch_nt_res(const ResArgs& g, size_t lds, hipStream_t st) {
+    auto kern = k_gemm_nt_res<NT, 1, RING>;
+    static bool raised[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {   // dynamic LDS above the default limit has to be requested once per device
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_MAX);
+        HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "gemm_nt: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        raised[dev] = true;
+    }
+    // One workgroup per compute unit; as many waves (<= 16) as there are tiles to hand out.
+    const int cus = cu_count();
+    int64_t wpb = hgv_cdiv(g.ntiles, cus);
+    if (wpb > 16) wpb = 16;
+    if (wpb < 1) wpb = 1;
+    int64_t blocks = hgv_cdiv(g.ntiles, wpb);
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), lds, st, g);
+    return HGV_OK;
 }
 
 bool a_ok(const float* p, int64_t ld, int K) { return p && hgv_aligned(p, 16) && ld % 4 == 0 && ld >= ((K + 3) / 4) * 4; }
@@ -367,8 +608,8 @@ void launch_tn(const WgArgs& g, int slices, hipStream_t st) {
 
 }  // namespace
 
-// Packed image of a weight for hgv_gemm_nt_packed: [rows][Kp] floats, rows = hgv_pack_rows(N),
-// Kp = ceil(K/32)*32, element (n,k) = W[n*sn + k*sk] inside [N][K] and zero outside.
+// Packed image of a weight for hgv_gemm_nt_packed: [Gp][rows][4] floats with rows = hgv_pack_rows(N),
+// Gp = ceil(K/32)*8 groups of 4 consecutive k; element (n,k) = W[n*sn + k*sk] inside [N][K], zero outside.
 extern "C" int hgv_pack_rows(int N) { return nt_template(N) * 16; }
 extern "C" size_t hgv_pack_bytes(int N, int K) { return hgv_align256((size_t)hgv_pack_rows(N) * kp_of(K) * 4); }
 
@@ -376,24 +617,25 @@ extern "C" int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, in
     HGV_REQUIRE(W && out && N > 0 && K > 0, HGV_EINVAL, "pack_weight: bad arguments");
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "pack_weight: N=%d > 288", N);
     HGV_REQUIRE(hgv_aligned(out, 16), HGV_EINVAL, "pack_weight: output must be 16-byte aligned");
-    const int rows = hgv_pack_rows(N), Kp = kp_of(K);
-    const int64_t total = (int64_t)rows * Kp;
-    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, W, sn, sk, N, K, out, rows, Kp);
+    const int rows = hgv_pack_rows(N), Gp = kp_of(K) / 4;
+    const int64_t total = (int64_t)rows * Gp * 4;
+    hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, W, sn, sk, N, K, out, rows, Gp);
     HGV_CHECK_LAUNCH("pack_weight");
     return HGV_OK;
 }
 
 // Writes one weight into rows [row_offset, row_offset + N) of a packed image that holds several
-// weights stacked along N (e.g. [W_l ; W_r] so that one product yields both halves).  The image has
-// hgv_pack_rows(total N) rows of ceil(K/32)*32 floats; rows not covered by any weight must be zero
-// (zero the buffer once when it is allocated).
+// weights stacked along N (e.g. [W_l ; W_r] so that one product yields both halves).  The image is
+// the one of a weight with n_total rows (hgv_pack_bytes(n_total, K) bytes); rows not covered by any
+// weight must be zero (zero the buffer once when it is allocated).
 extern "C" int hgv_pack_weight_rows(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, int row_offset,
-                                    hipStream_t stream) {
+                                    int n_total, hipStream_t stream) {
     HGV_REQUIRE(W && out && N > 0 && K > 0 && row_offset >= 0, HGV_EINVAL, "pack_weight_rows: bad arguments");
-    HGV_REQUIRE(row_offset + N <= 288, HGV_EUNSUPPORTED, "pack_weight_rows: more than 288 rows");
-    const int Kp = kp_of(K);
-    hipLaunchKernelGGL(k_pack_weight_rows, dim3((unsigned)hgv_cdiv((int64_t)N * Kp, 256)), dim3(256), 0, stream, W, sn, sk,
-                       N, K, out, row_offset, Kp);
+    HGV_REQUIRE(row_offset + N <= n_total && n_total <= 288, HGV_EUNSUPPORTED,
+                "pack_weight_rows: rows [%d, %d) outside an image of %d (<= 288) rows", row_offset, row_offset + N, n_total);
+    const int Gp = kp_of(K) / 4;
+    hipLaunchKernelGGL(k_pack_weight_rows, dim3((unsigned)hgv_cdiv((int64_t)N * Gp * 4, 256)), dim3(256), 0, stream, W, sn,
+                       sk, N, K, out, row_offset, hgv_pack_rows(n_total), Gp);
     HGV_CHECK_LAUNCH("pack_weight_rows");
     return HGV_OK;
 }
@@ -409,17 +651,38 @@ extern "C" int hgv_gemm_nt_packed(const float* A1, int64_t lda1, int K1, const f
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_nt: N=%d > 288", N);
     HGV_REQUIRE(a_ok(A1, lda1, K1) && Wp1 && hgv_aligned(Wp1, 16) && C && ldc >= N, HGV_EINVAL,
                 "gemm_nt: bad/misaligned buffer (source 1)");
-    GemmArgs g{};
-    g.s[0] = GemmSrc{A1, lda1, K1, Wp1, kp_of(K1)};
-    g.nsrc = 1;
-    if (A2) {
+    if (A2)
         HGV_REQUIRE(K2 > 0 && a_ok(A2, lda2, K2) && Wp2 && hgv_aligned(Wp2, 16), HGV_EINVAL,
                     "gemm_nt: bad/misaligned buffer (source 2)");
-        g.s[1] = GemmSrc{A2, lda2, K2, Wp2, kp_of(K2)};
-        g.nsrc = 2;
+    const int nt = nt_template(N), R = nt * 16;
+    const int G1 = (K1 + 3) / 4, G2 = A2 ? (K2 + 3) / 4 : 0;
+    const size_t lds = res_lds_bytes(R, G1, G2);
+    if (lds <= RES_LDS_MAX && hgv_aligned(C, 16) && ldc % 4 == 0) {
+        ResArgs g{};
+        g.s[0] = ResSrc{A1, lda1, G1, Wp1};
+        g.nsrc = 1;
+        if (A2) { g.s[1] = ResSrc{A2, lda2, G2, Wp2}; g.nsrc = 2; }
+        g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.ntiles = hgv_cdiv(M, 16);
+        // ring depth: 3 when it divides the tile's step count, else 2 (odd counts get one padding step)
+        const int Q = host_quads(G1) + host_quads(G2);
+        const bool r3 = Q % 3 == 0;
+        int rc = HGV_OK;
+#define HGV_RES(n) case n: rc = r3 ? launch_nt_res<n, 3>(g, lds, stream) : launch_nt_res<n, 2>(g, lds, stream); break;
+        switch (nt) {
+            HGV_RES(1) HGV_RES(2) HGV_RES(4) HGV_RES(7) HGV_RES(9) HGV_RES(12) HGV_RES(16)
+            default: rc = r3 ? launch_nt_res<18, 3>(g, lds, stream) : launch_nt_res<18, 2>(g, lds, stream); break;
+        }
+#undef HGV_RES
+        if (rc != HGV_OK) return rc;
+        HGV_CHECK_LAUNCH("gemm_nt (resident weights)");
+        return HGV_OK;
     }
+    GemmArgs g{};
+    g.s[0] = GemmSrc{A1, lda1, K1, Wp1};
+    g.nsrc = 1;
+    if (A2) { g.s[1] = GemmSrc{A2, lda2, K2, Wp2}; g.nsrc = 2; }
     g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N;
-    switch (nt_template(N)) {
+    switch (nt) {
         case 1: launch_nt<1>(g, stream); break;
         case 2: launch_nt<2>(g, stream); break;
         case 4: launch_nt<4>(g, stream); break;

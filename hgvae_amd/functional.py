@@ -226,7 +226,7 @@ def _packed_stack(wl: torch.Tensor, wr: torch.Tensor) -> torch.Tensor:
         buf = torch.zeros(_lib.load().hgv_pack_bytes(2 * n, k) // 4, dtype=torch.float32, device=wl.device)
     for w, off in ((wl, 0), (wr, n)):
         _lib.call("hgv_pack_weight_rows", w.data_ptr(), w.stride(0), w.stride(1), n, k, buf.data_ptr(), off,
-                  _lib.stream())
+                  2 * n, _lib.stream())
     _pack_cache[key] = (weakref.ref(wl, lambda _r, kk=key: _pack_cache.pop(kk, None)), sig, buf)
     return buf
 

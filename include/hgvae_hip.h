@@ -177,10 +177,10 @@ int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* o
 int hgv_pack_rows(int N);
 size_t hgv_pack_bytes(int N, int K);
 int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, hgv_stream_t stream);
-/* One weight into rows [row_offset, row_offset+N) of a packed image stacking several weights along N
- * (rows of the image not covered by a weight must be zero). */
+/* One weight into rows [row_offset, row_offset+N) of the packed image of an [n_total, K] weight that stacks
+ * several weights along N (rows of the image not covered by a weight must be zero). */
 int hgv_pack_weight_rows(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, int row_offset,
-                         hgv_stream_t stream);
+                         int n_total, hgv_stream_t stream);
 int hgv_gemm_nt_packed(const float* A1, int64_t lda1, int K1, const float* Wp1, const float* A2, int64_t lda2, int K2,
                        const float* Wp2, const float* bias, int64_t M, int N, float* C, int64_t ldc,
                        hgv_stream_t stream);

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Times the fp32 MFMA projection kernels on the benchmark shapes (events on the launching stream)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hgvae_amd import functional as Fn  # noqa: E402
+from hgvae_amd.graph import new_padded  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    m = int(os.environ.get("M", 160984))
+    shapes = [(138, 138, 138), (138, None, 138), (105, 105, 138), (138, 138, 56), (276, None, 138), (28, None, 138)]
+    only = os.environ.get("ONLY")
+    if only is not None:
+        shapes = [shapes[int(only)]]
+    for k1, k2, n in shapes:
+        xa = new_padded(m, k1, dev); xa.normal_()
+        xb = None
+        if k2:
+            xb = new_padded(m, k2, dev); xb.normal_()
+        w = torch.randn(n, k1 + (k2 or 0), device=dev)
+        wa, wb = w[:, :k1], (w[:, k1:] if k2 else None)
+        bias = torch.randn(n, device=dev)
+        g = new_padded(m, n, dev); g.normal_()
+        t_nt = timeit(lambda: Fn._gemm_nt(xa, wa, False, xb, wb, bias, n))
+        fl = 2.0 * m * (k1 + (k2 or 0)) * n
+        t_tn = timeit(lambda: Fn._gemm_tn(g, xa, True))
+        fl_tn = 2.0 * m * n * k1
+        print(f"NT M={m} K=({k1},{k2}) N={n}: {t_nt:7.1f} us {fl / t_nt / 1e6:6.1f} TF/s | "
+              f"TN N={n} K={k1}: {t_tn:7.1f} us {fl_tn / t_tn / 1e6:6.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
