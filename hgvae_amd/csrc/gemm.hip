@@ -367,164 +367,238 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_nt(const GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------
-// TN kernel (weight gradient)
+// TN kernel (weight gradient): operands straight from global memory, no LDS in the main loop
 // ------------------------------------------------------------------------------------------
-constexpr int T_BM = 32;        // rows (reduction index) per LDS stage
-
-struct WgArgs {
+// GW[n][k] = sum_m G[m][n] A[m][k].  One MFMA step reduces 4 rows m: lane (i, kq) supplies row
+// m0 + kq.  A lane loads WN consecutive columns of G (per n block) and WK consecutive columns of A
+// with one wide load each (16 lanes = 16*WN contiguous floats of a row) and uses element r of a G
+// load with element c of the A load in MFMA (r, c) - tile (r, c) therefore holds the output rows
+// n = n0 + WN*i' + r and columns k = k0 + WK*j' + c, an interleaving that the reduction kernel
+// undoes when it writes the final matrix.  A wave owns NB n blocks x one k block (NB*WN*WK tiles,
+// up to 27) of one row slice; its loads run RING steps ahead of the MFMAs.  The kernel is bound by
+// the rate at which a compute unit's L1 can be filled from L2, so the tile per wave is made as
+// large as the registers allow: G is re-read once per k block, A once per group of n blocks.
+// The waves of a workgroup work on consecutive row slices of the same tiles and add their
+// accumulators through LDS at the end (a tree, fixed order), which divides the number of partial
+// tile sets that go through memory.
+//
+// A lane whose first column is past the matrix reads column 0 instead; a lane at the edge may read
+// up to 3 floats past its row's leading dimension, i.e. the start of the next row.  To keep that
+// inside the buffer, and to keep every slice a whole number of 4-row steps, this kernel covers the
+// rows [0, Mf) with Mf = 4*floor((M-1)/4); the outer products of the last 1..4 rows are added by
+// the reduction kernel.  Columns past the matrix are not masked: they only reach output elements
+// that are never stored.
+struct TdArgs {
     const float* G; int64_t ldg; int N;
     const float* A; int64_t lda; int K;
-    int64_t M; int64_t rows_per_slice;
-    float* partial;        // [slices][N*K]
-    float* bias_partial;   // [slices][N] or null
+    int64_t Mf;                 // rows covered here: 4*floor((M-1)/4)
+    int64_t rows_per_slice;     // rows per wave, multiple of 4
+    int sets;                   // workgroup slices = partial tile sets
+    int ngrp, kblk;             // groups of NB n blocks, k blocks
+    float* partial;             // [sets][ngrp*kblk][NB*WN*WK][4][64]
+    float* bias_partial;        // [sets][ngrp][NB*WN][16] or null
 };
 
-// A workgroup owns NTL x KT output tiles (16x16 each) for one slice of rows; the tiles are dealt
-// round-robin to its 4 waves (tile t -> wave t % 4), which balances odd tile counts (9 x 9 = 81).
-template <int NTL, int KT>
-__global__ __launch_bounds__(256) void k_gemm_tn(const WgArgs g) {
-    constexpr int NB = NTL * 16, KB = KT * 16;
-    constexpr int GS_LD = NB + ((NTL & 1) ? 0 : 16);   // == 16 mod 32: rows r, r+1 fall on disjoint banks
-    constexpr int AS_LD = KB + ((KT & 1) ? 0 : 16);
-    constexpr int TT = NTL * KT, TPW = (TT + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float Gs[T_BM * GS_LD];
-    __shared__ __attribute__((aligned(16))) float As[T_BM * AS_LD];
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int i = lane & 15, kq = lane >> 4;
-    const int n_base = blockIdx.z * NB, k_base = blockIdx.y * KB;
-    const int64_t m_lo = (int64_t)blockIdx.x * g.rows_per_slice;
-    const int64_t m_hi = min(g.M, m_lo + g.rows_per_slice);
+// W floats from a 4-byte aligned address as one load.  The vector has exactly W live elements: a
+// dead element of a wider load gets reused as a temporary register, and writing it forces a wait
+// for the load that is still in flight.
+template <int W> struct TdVec;
+template <> struct TdVec<1> { typedef float T; typedef float U __attribute__((aligned(4))); static __device__ __forceinline__ float at(T v, int) { return v; } };
+template <> struct TdVec<2> { typedef float T __attribute__((ext_vector_type(2))); typedef float U __attribute__((ext_vector_type(2), aligned(4))); static __device__ __forceinline__ float at(T v, int r) { return v[r]; } };
+template <> struct TdVec<3> { typedef float T __attribute__((ext_vector_type(3))); typedef float U __attribute__((ext_vector_type(3), aligned(4))); static __device__ __forceinline__ float at(T v, int r) { return v[r]; } };
+template <> struct TdVec<4> { typedef float T __attribute__((ext_vector_type(4))); typedef float U __attribute__((ext_vector_type(4), aligned(4))); static __device__ __forceinline__ float at(T v, int r) { return v[r]; } };
 
-    f32x4 acc[TPW];
+template <int WN, int NB, int WK, int RING>
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // (waves/2) x (tiles x 256 + NB*WN x 64) floats
+    constexpr int TN_ = NB * WN, TILES = TN_ * WK;
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), spw = blockDim.x >> 6;
+    // workgroups go round-robin over the 8 XCDs: give every XCD whole row slices, so that the
+    // workgroups sharing rows also share an L2
+    const int per = g.ngrp * g.kblk;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int set = (idx / per) * 8 + xcd, blk = idx % per;
+    if (set >= g.sets) return;                       // whole workgroup: no barrier is skipped by part of it
+    const int zb = blk / g.kblk, yb = blk - zb * g.kblk;
+    const int k0 = yb * 16 * WK + WK * i;
+    const int64_t m_lo = min(g.Mf, ((int64_t)set * spw + w) * g.rows_per_slice);
+    const int64_t m_hi = min(g.Mf, m_lo + g.rows_per_slice);
+    // Per-lane byte offsets inside a 4-row step (constant for the whole kernel); the step's base
+    // address is wave-uniform, so the per-step address arithmetic is scalar.
+    uint32_t goff[NB];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-
-    constexpr int GV = T_BM * (NB / 4), AV = T_BM * (KB / 4);   // float4 pieces per stage
-    constexpr int GQ = (GV + 255) / 256, AQ = (AV + 255) / 256;
-    f32x4 rg[GQ], ra[AQ];
-    const int n_last = ((g.N - 1) >> 2) << 2, k_last = ((g.K - 1) >> 2) << 2;
-
-    auto load_stage = [&](int64_t m0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const int e = min(t + 256 * q, GV - 1);
-            const int r = e / (NB / 4), c4 = e - r * (NB / 4);
-            rg[q] = *reinterpret_cast<const f32x4*>(g.G + min(m0 + r, g.M - 1) * g.ldg + min(n_base + 4 * c4, n_last));
-        }
-#pragma unroll
-        for (int q = 0; q < AQ; ++q) {
-            const int e = min(t + 256 * q, AV - 1);
-            const int r = e / (KB / 4), c4 = e - r * (KB / 4);
-            ra[q] = *reinterpret_cast<const f32x4*>(g.A + min(m0 + r, g.M - 1) * g.lda + min(k_base + 4 * c4, k_last));
-        }
-    };
-    // invalid rows / columns are zeroed by multiplying with a 0/1 mask on the way to LDS
-    auto store_stage = [&](int64_t m0) __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            const int e = t + 256 * q;
-            const int r = e / (NB / 4), c4 = e - r * (NB / 4);
-            const int col = n_base + 4 * c4;
-            const float rm = m0 + r < m_hi ? 1.f : 0.f;
-            const f32x4 mk = {col + 0 < g.N ? rm : 0.f, col + 1 < g.N ? rm : 0.f, col + 2 < g.N ? rm : 0.f,
-                              col + 3 < g.N ? rm : 0.f};
-            if (e < GV) *reinterpret_cast<f32x4*>(&Gs[r * GS_LD + 4 * c4]) = rg[q] * mk;
-        }
-#pragma unroll
-        for (int q = 0; q < AQ; ++q) {
-            const int e = t + 256 * q;
-            const int r = e / (KB / 4), c4 = e - r * (KB / 4);
-            const int col = k_base + 4 * c4;
-            const float rm = m0 + r < m_hi ? 1.f : 0.f;
-            const f32x4 mk = {col + 0 < g.K ? rm : 0.f, col + 1 < g.K ? rm : 0.f, col + 2 < g.K ? rm : 0.f,
-                              col + 3 < g.K ? rm : 0.f};
-            if (e < AV) *reinterpret_cast<f32x4*>(&As[r * AS_LD + 4 * c4]) = ra[q] * mk;
-        }
-    };
-
-    // Wave-specialised MFMA body: with W a compile-time constant every tile's (n-tile, k-tile) pair
-    // is static, so the accumulators stay in registers and unused fragment loads disappear.
-    auto compute_w = [&](auto wc) __attribute__((always_inline)) {
-        constexpr int W = decltype(wc)::value;
-#pragma unroll
-        for (int st = 0; st < T_BM / 4; ++st) {
-            float ga[NTL], ab[KT];
-#pragma unroll
-            for (int a = 0; a < NTL; ++a) ga[a] = Gs[(4 * st + kq) * GS_LD + 16 * a + i];
-#pragma unroll
-            for (int b = 0; b < KT; ++b) ab[b] = As[(4 * st + kq) * AS_LD + 16 * b + i];
-#pragma unroll
-            for (int j = 0; j < TPW; ++j) {
-                const int tile = W + 4 * j;
-                if (tile < TT) acc[j] = MFMA16(ga[tile / KT], ab[tile % KT], acc[j]);
-            }
-        }
-    };
-    auto compute = [&]() __attribute__((always_inline)) {
-        if (g.bias_partial && blockIdx.y == 0 && t < NB) {
-#pragma unroll 8
-            for (int r = 0; r < T_BM; ++r) bsum += Gs[r * GS_LD + t];
-        }
-        if (w == 0) compute_w(std::integral_constant<int, 0>{});
-        else if (w == 1) compute_w(std::integral_constant<int, 1>{});
-        else if (w == 2) compute_w(std::integral_constant<int, 2>{});
-        else compute_w(std::integral_constant<int, 3>{});
-    };
-
-    bool have = false;
-    for (int64_t m0 = m_lo; m0 < m_hi; m0 += T_BM) {
-        load_stage(m0);
-        if (have) compute();
-        __syncthreads();
-        store_stage(m0);
-        __syncthreads();
-        have = true;
+    for (int b = 0; b < NB; ++b) {
+        const int n0 = (zb * NB + b) * 16 * WN + WN * i;
+        goff[b] = (uint32_t)(((int64_t)kq * g.ldg + (n0 < g.N ? n0 : 0)) * 4);
     }
-    if (have) compute();
+    const uint32_t aoff = (uint32_t)(((int64_t)kq * g.lda + (k0 < g.K ? k0 : 0)) * 4);
+    const char* gbytes = reinterpret_cast<const char*>(g.G);
+    const char* abytes = reinterpret_cast<const char*>(g.A);
 
-    float* out = g.partial + (int64_t)blockIdx.x * g.N * g.K;
+    f32x4 acc[TN_][WK];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-        const int tile = w + 4 * j;
-        if (tile < TT) {
-            const int a = tile / KT, b = tile - a * KT;
-            const int k = k_base + 16 * b + i;
+    for (int r = 0; r < TN_; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n_base + 16 * a + 4 * kq + r;
-                if (n < g.N && k < g.K) out[(int64_t)n * g.K + k] = acc[j][r];
+        for (int c = 0; c < WK; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[TN_];
+#pragma unroll
+    for (int r = 0; r < TN_; ++r) bsum[r] = 0.f;
+
+    typename TdVec<WN>::T gr[RING][NB];
+    typename TdVec<WK>::T ar[RING];
+    int64_t lm = m_lo;           // load cursor (wave-uniform); past the covered rows it re-reads the last step
+    auto issue = [&](int d) __attribute__((always_inline)) {
+        const int64_t r0 = min(lm, g.Mf - 4);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            gr[d][b] = *reinterpret_cast<const typename TdVec<WN>::U*>(gbytes + r0 * g.ldg * 4 + goff[b]);
+        ar[d] = *reinterpret_cast<const typename TdVec<WK>::U*>(abytes + r0 * g.lda * 4 + aoff);
+        lm += 4;
+    };
+    const int steps = (int)((m_hi - m_lo) >> 2);                 // slices hold whole steps
+    const int steps_p = (steps + RING - 1) / RING * RING;         // whole ring rounds; the extra steps are masked
+#pragma unroll
+    for (int d = 0; d < RING; ++d) {
+        issue(d);
+        __builtin_amdgcn_sched_barrier(0);   // slot order = issue order, or the first wait in the loop drains the ring
+    }
+    for (int s0 = 0; s0 < steps_p; s0 += RING) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            typename TdVec<WN>::T gv[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) gv[b] = gr[d][b];
+            const typename TdVec<WK>::T av = ar[d];
+            issue(d);
+            const bool live = s0 + d < steps;      // wave-uniform
+            float ga[TN_];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < WN; ++r) ga[b * WN + r] = live ? TdVec<WN>::at(gv[b], r) : 0.f;
+#pragma unroll
+            for (int r = 0; r < TN_; ++r) {
+#pragma unroll
+                for (int c = 0; c < WK; ++c) acc[r][c] = MFMA16(ga[r], TdVec<WK>::at(av, c), acc[r][c]);
+                bsum[r] += ga[r];
             }
+            // keep every slot's load where it is written: moved to the end of the unrolled body it
+            // would be consumed right after the loop back-edge
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (g.bias_partial && blockIdx.y == 0 && t < NB && n_base + t < g.N)
-        g.bias_partial[(int64_t)blockIdx.x * g.N + n_base + t] = bsum;
+
+    // column sums: add the 4 row groups of the wave
+#pragma unroll
+    for (int r = 0; r < TN_; ++r) {
+        bsum[r] += __shfl_xor(bsum[r], 16, 64);
+        bsum[r] += __shfl_xor(bsum[r], 32, 64);
+    }
+    // tree over the workgroup's waves: the upper half of the active waves writes, the lower half adds
+    constexpr int SLOT = TILES * 256 + TN_ * 64;
+    for (int half = spw >> 1; half >= 1; half >>= 1) {
+        if (w >= half && w < 2 * half) {
+            float* dst = red + (int64_t)(w - half) * SLOT;
+#pragma unroll
+            for (int r = 0; r < TN_; ++r) {
+#pragma unroll
+                for (int c = 0; c < WK; ++c)
+                    *reinterpret_cast<f32x4*>(dst + ((r * WK + c) * 64 + lane) * 4) = acc[r][c];
+                dst[TILES * 256 + r * 64 + lane] = bsum[r];
+            }
+        }
+        __syncthreads();
+        if (w < half) {
+            const float* src = red + (int64_t)w * SLOT;
+#pragma unroll
+            for (int r = 0; r < TN_; ++r) {
+#pragma unroll
+                for (int c = 0; c < WK; ++c)
+                    acc[r][c] += *reinterpret_cast<const f32x4*>(src + ((r * WK + c) * 64 + lane) * 4);
+                bsum[r] += src[TILES * 256 + r * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (w == 0) {
+        float* out = g.partial + ((int64_t)set * per + blk) * (TILES * 256);
+#pragma unroll
+        for (int r = 0; r < TN_; ++r)
+#pragma unroll
+            for (int c = 0; c < WK; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[((r * WK + c) * 4 + q) * 64 + lane] = acc[r][c][q];
+        if (g.bias_partial && yb == 0 && kq == 0) {
+            float* bo = g.bias_partial + ((int64_t)set * g.ngrp + zb) * (TN_ * 16);
+#pragma unroll
+            for (int r = 0; r < TN_; ++r) bo[r * 16 + i] = bsum[r];
+        }
+    }
 }
 
-// out[e] = sum over slices of partial[s][e].  A workgroup handles 32 elements x 8 slice groups;
+// Final matrix from the partial tile sets: GW[n][k] = sum over sets (fixed order, fp64) of the
+// tile element that holds (n, k), plus the products of the last 1..4 rows; after the tile elements
+// come the bias elements (column sums of G).  A workgroup handles 64 elements x 4 groups of sets;
 // group sums are combined through LDS in a fixed order, so the result is reproducible.
-__global__ __launch_bounds__(256) void k_reduce_slices(const float* __restrict__ partial, int slices, int64_t count,
-                                                       float* __restrict__ out) {
-    __shared__ double sh[8][33];
-    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int64_t e = (int64_t)blockIdx.x * 32 + el;
-    double s0 = 0.0, s1 = 0.0;
-    if (e < count) {
+struct TrArgs {
+    const float* partial; const float* bias_partial; int sets;
+    int wn, nb, wk, ngrp, kblk;
+    const float* g_last; const float* a_last;      // first of the last rows of G and of A (not covered by the tiles)
+    int64_t ldg, lda; int n_last;                   // 1..4 such rows
+    int N, K;
+    float* GW; float* gbias;
+};
+
+__global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
+    __shared__ double sh[4][65];
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int tn = g.nb * g.wn;
+    const int64_t tile_elems = (int64_t)g.ngrp * g.kblk * tn * g.wk * 256;
+    const int64_t bias_elems = (int64_t)g.ngrp * tn * 16;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    const bool is_bias = e >= tile_elems;
+    const int64_t eb = e - tile_elems;
+    const bool live = !is_bias || (g.gbias != nullptr && eb < bias_elems);
+    const float* src = is_bias ? g.bias_partial + eb : g.partial + e;
+    const int64_t stride = is_bias ? bias_elems : tile_elems;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (live) {
         int k = grp;
-        for (; k + 8 < slices; k += 16) {
-            s0 += (double)partial[(int64_t)k * count + e];
-            s1 += (double)partial[(int64_t)(k + 8) * count + e];
+        for (; k + 12 < g.sets; k += 16) {
+            s0 += (double)src[(int64_t)k * stride];
+            s1 += (double)src[(int64_t)(k + 4) * stride];
+            s2 += (double)src[(int64_t)(k + 8) * stride];
+            s3 += (double)src[(int64_t)(k + 12) * stride];
         }
-        if (k < slices) s0 += (double)partial[(int64_t)k * count + e];
+        for (; k < g.sets; k += 4) s0 += (double)src[(int64_t)k * stride];
     }
-    sh[grp][el] = s0 + s1;
+    sh[grp][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (grp == 0 && e < count) {
-        double s = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s += sh[q][el];
-        out[e] = (float)s;
+    if (grp == 0 && live) {
+        double v = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
+        if (is_bias) {
+            const int zb = (int)(eb / (tn * 16)), rem = (int)(eb - (int64_t)zb * tn * 16);
+            const int rr = rem >> 4, b = rr / g.wn, r = rr - b * g.wn;
+            const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (rem & 15) + r;
+            if (n < g.N) {
+                for (int q = 0; q < g.n_last; ++q) v += (double)g.g_last[q * g.ldg + n];
+                g.gbias[n] = (float)v;
+            }
+        } else {
+            const int per_tile = tn * g.wk * 256;
+            const int blk = (int)(e / per_tile), rem = (int)(e - (int64_t)blk * per_tile);
+            const int t = rem >> 8, q = (rem >> 6) & 3, lane = rem & 63;
+            const int rr = t / g.wk, c = t - rr * g.wk;
+            const int b = rr / g.wn, r = rr - b * g.wn;
+            const int zb = blk / g.kblk, yb = blk - zb * g.kblk;
+            const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (4 * (lane >> 4) + q) + r;
+            const int k = yb * 16 * g.wk + g.wk * (lane & 15) + c;
+            if (n < g.N && k < g.K) {
+                for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)g.a_last[q2 * g.lda + k];
+                g.GW[(int64_t)n * g.K + k] = (float)v;
+            }
+        }
     }
 }
 
@@ -585,25 +659,71 @@ int launch_nt_res(const ResArgs& g, size_t lds, hipStream_t st) {
 
 bool a_ok(const float* p, int64_t ld, int K) { return p && hgv_aligned(p, 16) && ld % 4 == 0 && ld >= ((K + 3) / 4) * 4; }
 
-void pick_tn(int N, int K, int* ntl, int* kt) {
-    const int ntiles = (N + 15) / 16, ktiles = (K + 15) / 16;
-    *ntl = ntiles <= 1 ? 1 : ntiles <= 2 ? 2 : ntiles <= 4 ? 4 : ntiles <= 7 ? 7 : ntiles <= 9 ? 9 : 12;
-    *kt = ktiles <= 2 ? 2 : (ktiles <= 4 ? 4 : (ktiles <= 7 ? 7 : 9));
+// padded width of a dimension covered by blocks of 16*w columns
+int td_pad(int n, int w) { return (int)hgv_cdiv(n, 16 * w) * 16 * w; }
+
+// columns per lane (1..wmax) for a matrix dimension: least padding (ties: wider), at least 2 when
+// the dimension has more than one tile
+int td_width(int n, int wmax) {
+    if (n <= 16 || wmax < 2) return 1;
+    int best = 2;
+    for (int w = 3; w <= wmax; ++w)
+        if (td_pad(n, w) <= td_pad(n, best)) best = w;
+    return best;
 }
 
-int tn_slices(int64_t M, int N, int K, int ntl, int kt) {
-    const int gz = (int)hgv_cdiv(N, ntl * 16), gy = (int)hgv_cdiv(K, kt * 16);
-    int64_t s = 512 / (gz * gy);
-    const int64_t max_s = hgv_cdiv(M, 64);
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    return (int)s;
+struct TdPlan {
+    int wn, nb, wk, ngrp, kblk;      // tile shape per wave and block counts
+    int sets, spw;                   // workgroups along the rows, waves per workgroup
+    int64_t rows_per_slice;          // rows per wave
+    int64_t tile_elems, bias_elems;  // floats per partial set
+};
+
+TdPlan td_plan(int64_t M, int N, int K) {
+    TdPlan p{};
+    p.wn = td_width(N, 4);
+    const int nblk = (int)hgv_cdiv(N, 16 * p.wn);
+    p.nb = nblk < 3 ? nblk : 3;                               // n blocks per wave
+    int wkmax = 27 / (p.nb * p.wn);
+    if (wkmax > 4) wkmax = 4;
+    if (wkmax < 2 && p.nb > 1) { p.nb = 1; wkmax = 4; }       // very wide N: one block per wave, wide k
+    p.wk = td_width(K, wkmax);
+    p.ngrp = (int)hgv_cdiv(nblk, p.nb);
+    p.kblk = (int)hgv_cdiv(K, 16 * p.wk);
+    const int tn = p.nb * p.wn;
+    p.tile_elems = (int64_t)p.ngrp * p.kblk * tn * p.wk * 256;
+    p.bias_elems = (int64_t)p.ngrp * tn * 16;
+    const int64_t Mf = (M - 1) / 4 * 4;
+    p.spw = 1; p.rows_per_slice = 4;
+    if (Mf <= 0) { p.sets = 0; return p; }
+    // two workgroups of four waves per compute unit; every wave gets at least 32 rows
+    const int64_t per = (int64_t)p.ngrp * p.kblk;
+    int64_t slices = hgv_cdiv(Mf, 32);                        // most row slices the rows allow
+    int spw = 4;
+    while (spw > 1 && slices < spw) spw >>= 1;
+    // workgroups (sets x per, sets rounded up to whole XCD rounds) must not exceed the resident
+    // capacity: a few workgroups left over for a second round would double the time
+    int64_t sets = (int64_t)2 * cu_count() / per;
+    if (sets >= 8) sets = sets / 8 * 8;
+    if (sets * spw > slices) sets = slices / spw;
+    if (sets < 1) sets = 1;
+    p.spw = spw;
+    p.rows_per_slice = hgv_cdiv(hgv_cdiv(Mf, sets * spw), 4) * 4;
+    p.sets = (int)hgv_cdiv(Mf, p.rows_per_slice * spw);
+    return p;
 }
 
-template <int NTL, int KT>
-void launch_tn(const WgArgs& g, int slices, hipStream_t st) {
-    const int gz = (int)hgv_cdiv(g.N, NTL * 16), gy = (int)hgv_cdiv(g.K, KT * 16);
-    hipLaunchKernelGGL((k_gemm_tn<NTL, KT>), dim3(slices, gy, gz), dim3(256), 0, st, g);
+template <int WN, int NB, int WK>
+int launch_td(const TdArgs& g, int spw, hipStream_t st) {
+    constexpr int RING = (NB * WN + WK) * 6 <= 72 ? 6 : 5;
+    const int64_t blocks = hgv_cdiv(g.sets, 8) * 8 * g.ngrp * g.kblk;
+    size_t lds = (size_t)(spw >> 1) * (NB * WN * WK * 256 + NB * WN * 64) * sizeof(float);
+    HGV_REQUIRE(lds <= 64 * 1024, HGV_EUNSUPPORTED, "gemm_tn: reduction buffer of %zu bytes", lds);
+    // The dispatcher packs as many workgroups on a compute unit as its resources allow.  Asking
+    // for 64 KB of LDS caps that at two, which spreads a grid of 2 x CUs workgroups evenly.
+    if (blocks >= cu_count()) lds = 64 * 1024;
+    hipLaunchKernelGGL((k_gemm_tn_direct<WN, NB, WK, RING>), dim3((unsigned)blocks), dim3(64 * spw), lds, st, g);
+    return HGV_OK;
 }
 
 }  // namespace
@@ -725,42 +845,54 @@ extern "C" int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W
 
 extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 256;
-    int ntl, kt;
-    pick_tn(N, K, &ntl, &kt);
-    const int s = tn_slices(M, N, K, ntl, kt);
-    return hgv_align256((size_t)s * N * K * 4) + hgv_align256((size_t)s * N * 4);
+    const TdPlan p = td_plan(M, N, K);
+    const size_t sets = p.sets > 0 ? p.sets : 1;
+    return hgv_align256(sets * p.tile_elems * 4) + hgv_align256(sets * p.bias_elems * 4);
 }
 
 // GW[N,K] (row-major, ld = K) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
-// G and A must be 16-byte aligned with leading dimensions that are multiples of 4 and cover
-// ceil(cols/4)*4 columns.
+// G and A are row-major with leading dimensions >= their widths (any 4-byte aligned pointers).
 extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M,
                            float* GW, float* gbias, void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(M > 0 && N > 0 && K > 0, HGV_EINVAL, "gemm_tn: bad sizes");
-    HGV_REQUIRE(a_ok(G, ldg, N) && a_ok(A, lda, K) && GW && ws, HGV_EINVAL, "gemm_tn: bad/misaligned buffer");
+    HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
+    HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_tn: N=%d > 288", N);
+    HGV_REQUIRE(ldg < (1 << 27) && lda < (1 << 27), HGV_EUNSUPPORTED, "gemm_tn: leading dimension too large");
     HGV_REQUIRE(ws_bytes >= hgv_gemm_tn_ws(M, N, K) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
-    int ntl, kt;
-    pick_tn(N, K, &ntl, &kt);
-    const int s = tn_slices(M, N, K, ntl, kt);
-    WgArgs g{};
-    g.G = G; g.ldg = ldg; g.N = N; g.A = A; g.lda = lda; g.K = K; g.M = M;
-    g.rows_per_slice = hgv_cdiv(hgv_cdiv(M, s), T_BM) * T_BM;
-    const int slices = (int)hgv_cdiv(M, g.rows_per_slice);
-    g.partial = (float*)ws;
-    g.bias_partial = gbias ? (float*)((char*)ws + hgv_align256((size_t)s * N * K * 4)) : nullptr;
-#define HGV_TN(a, b) if (ntl == a && kt == b) launch_tn<a, b>(g, slices, stream);
-    HGV_TN(1, 2) HGV_TN(1, 4) HGV_TN(1, 7) HGV_TN(1, 9)
-    HGV_TN(2, 2) HGV_TN(2, 4) HGV_TN(2, 7) HGV_TN(2, 9)
-    HGV_TN(4, 2) HGV_TN(4, 4) HGV_TN(4, 7) HGV_TN(4, 9)
-    HGV_TN(7, 2) HGV_TN(7, 4) HGV_TN(7, 7) HGV_TN(7, 9)
-    HGV_TN(9, 2) HGV_TN(9, 4) HGV_TN(9, 7) HGV_TN(9, 9)
-    HGV_TN(12, 2) HGV_TN(12, 4) HGV_TN(12, 7) HGV_TN(12, 9)
-#undef HGV_TN
-    const int64_t cnt = (int64_t)N * K;
-    hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(cnt, 32)), dim3(256), 0, stream, g.partial, slices, cnt, GW);
-    if (gbias)
-        hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)hgv_cdiv(N, 32)), dim3(256), 0, stream, g.bias_partial, slices,
-                           (int64_t)N, gbias);
+    const TdPlan p = td_plan(M, N, K);
+    const size_t sets = p.sets > 0 ? p.sets : 1;
+    float* partial = (float*)ws;
+    float* bias_partial = (float*)((char*)ws + hgv_align256(sets * p.tile_elems * 4));
+    const int64_t Mf = (M - 1) / 4 * 4;
+    if (p.sets > 0) {
+        TdArgs g{};
+        g.G = G; g.ldg = ldg; g.N = N; g.A = A; g.lda = lda; g.K = K; g.Mf = Mf;
+        g.rows_per_slice = p.rows_per_slice; g.sets = p.sets; g.ngrp = p.ngrp; g.kblk = p.kblk;
+        g.partial = partial; g.bias_partial = gbias ? bias_partial : nullptr;
+        int rc = HGV_EUNSUPPORTED;
+        bool hit = false;
+#define HGV_TD(a, b, c) if (!hit && p.wn == a && p.nb == b && p.wk == c) { hit = true; rc = launch_td<a, b, c>(g, p.spw, stream); }
+        HGV_TD(1, 1, 1) HGV_TD(1, 1, 2) HGV_TD(1, 1, 3) HGV_TD(1, 1, 4)
+        HGV_TD(2, 1, 1) HGV_TD(2, 1, 2) HGV_TD(2, 1, 3) HGV_TD(2, 1, 4)
+        HGV_TD(2, 2, 1) HGV_TD(2, 2, 2) HGV_TD(2, 2, 3) HGV_TD(2, 2, 4)
+        HGV_TD(2, 3, 1) HGV_TD(2, 3, 2) HGV_TD(2, 3, 3) HGV_TD(2, 3, 4)
+        HGV_TD(3, 1, 1) HGV_TD(3, 1, 2) HGV_TD(3, 1, 3) HGV_TD(3, 1, 4)
+        HGV_TD(3, 2, 1) HGV_TD(3, 2, 2) HGV_TD(3, 2, 3) HGV_TD(3, 2, 4)
+        HGV_TD(3, 3, 1) HGV_TD(3, 3, 2) HGV_TD(3, 3, 3)
+        HGV_TD(4, 1, 1) HGV_TD(4, 1, 2) HGV_TD(4, 1, 3) HGV_TD(4, 1, 4)
+        HGV_TD(4, 2, 1) HGV_TD(4, 2, 2) HGV_TD(4, 2, 3)
+        HGV_TD(4, 3, 1) HGV_TD(4, 3, 2)
+#undef HGV_TD
+        HGV_REQUIRE(hit, HGV_EUNSUPPORTED, "gemm_tn: no kernel for tile shape (%d,%d,%d)", p.wn, p.nb, p.wk);
+        if (rc != HGV_OK) return rc;
+    }
+    TrArgs r{};
+    r.partial = partial; r.bias_partial = bias_partial; r.sets = p.sets;
+    r.wn = p.wn; r.nb = p.nb; r.wk = p.wk; r.ngrp = p.ngrp; r.kblk = p.kblk;
+    r.g_last = G + Mf * ldg; r.a_last = A + Mf * lda; r.ldg = ldg; r.lda = lda; r.n_last = (int)(M - Mf);
+    r.N = N; r.K = K; r.GW = GW; r.gbias = gbias;
+    const int64_t elems = p.tile_elems + (gbias ? p.bias_elems : 0);
+    hipLaunchKernelGGL(k_reduce_tn, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn");
     return HGV_OK;
 }
