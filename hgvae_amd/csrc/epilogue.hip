@@ -141,8 +141,33 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
 }
 
 // One workgroup = 16 columns x 64 slices of the partial list; slices are combined through LDS
-// in a fixed order, so the result does not depend on scheduling.
+// in a fixed order (64 -> 8 -> 1), so the result does not depend on scheduling.
 constexpr int FIN_SL = 64;
+
+// sums the FIN_SL per-slice values of column cl; valid in the threads with sl == 0
+__device__ __forceinline__ double fin_tree(double (*sh)[17], int sl, int cl, double v) {
+    sh[sl][cl] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (sl < 8) {
+#pragma unroll
+        for (int q = 0; q < FIN_SL / 8; ++q) s += sh[sl + 8 * q][cl];
+    }
+    __syncthreads();
+    if (sl < 8) sh[sl][cl] = s;
+    __syncthreads();
+    s = 0.0;
+    if (sl == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += sh[q][cl];
+    }
+    __syncthreads();
+    return s;
+}
+
+// Per-block (mean_b, M2_b) -> batch mean and variance in one pass over the partial list: with the
+// pivot p = mean of block 0 and d_b = mean_b - p,
+//   mean = p + sum(n_b d_b) / N,   M2 = sum(M2_b + n_b d_b^2) - (sum n_b d_b)^2 / N      (fp64).
 __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks,
                                                            int64_t rows_per_block, int64_t N, int H, int Hp,
                                                            float eps, float momentum,
@@ -154,36 +179,35 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < H;
-    double acc = 0.0;
+    double a1 = 0.0, a2 = 0.0, pivot = 0.0;
     if (ok) {
-        for (int b = sl; b < nblocks; b += FIN_SL) {
-            const int64_t r0 = (int64_t)b * rows_per_block;
-            const double nb = (double)(min(N, r0 + rows_per_block) - r0);
-            acc += nb * (double)partial[((int64_t)b * 2) * Hp + c];
-        }
-    }
-    sh[sl][cl] = acc;
-    __syncthreads();
-    double msum = 0.0;
+        pivot = (double)partial[c];
+        const double n_full = (double)rows_per_block;
+        const double n_tail = (double)(N - (int64_t)(nblocks - 1) * rows_per_block);
+        // batches of 8 independent loads (clamped index, zero weight past the end) before the fp64 chain
+        for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
+            float m[8], q[8];
 #pragma unroll
-    for (int s = 0; s < FIN_SL; ++s) msum += sh[s][cl];
-    const double mean = msum / (double)N;
-    __syncthreads();
-    acc = 0.0;
-    if (ok) {
-        for (int b = sl; b < nblocks; b += FIN_SL) {
-            const int64_t r0 = (int64_t)b * rows_per_block;
-            const double nb = (double)(min(N, r0 + rows_per_block) - r0);
-            const double dm = (double)partial[((int64_t)b * 2) * Hp + c] - mean;
-            acc += (double)partial[((int64_t)b * 2 + 1) * Hp + c] + nb * dm * dm;
+            for (int u = 0; u < 8; ++u) {
+                const int b = min(b0 + u * FIN_SL, nblocks - 1);
+                m[u] = partial[((int64_t)b * 2) * Hp + c];
+                q[u] = partial[((int64_t)b * 2 + 1) * Hp + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * FIN_SL;
+                const double nb = b >= nblocks ? 0.0 : (b == nblocks - 1 ? n_tail : n_full);
+                const double d = (double)m[u] - pivot;
+                a1 += nb * d;
+                a2 += (b < nblocks ? (double)q[u] : 0.0) + nb * d * d;
+            }
         }
     }
-    sh[sl][cl] = acc;
-    __syncthreads();
+    const double s1 = fin_tree(sh, sl, cl, a1);
+    const double s2 = fin_tree(sh, sl, cl, a2);
     if (sl != 0 || !ok) return;
-    double m2 = 0.0;
-#pragma unroll
-    for (int s = 0; s < FIN_SL; ++s) m2 += sh[s][cl];
+    const double mean = pivot + s1 / (double)N;
+    double m2 = s2 - s1 * s1 / (double)N;
     if (m2 < 0.0) m2 = 0.0;
     const double var = m2 / (double)N;
     save_mean[c] = (float)mean;
@@ -277,23 +301,30 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
 __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
                                                          int Hp, float* __restrict__ sums,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double sh1[FIN_SL][17];
-    __shared__ double sh2[FIN_SL][17];
+    __shared__ double sh[FIN_SL][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < H) {
-        for (int b = sl; b < nblocks; b += FIN_SL) {
-            a1 += (double)partial[((int64_t)b * 2 + 0) * Hp + c];
-            a2 += (double)partial[((int64_t)b * 2 + 1) * Hp + c];
+        for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
+            float m[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = min(b0 + u * FIN_SL, nblocks - 1);
+                m[u] = partial[((int64_t)b * 2 + 0) * Hp + c];
+                q[u] = partial[((int64_t)b * 2 + 1) * Hp + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = b0 + u * FIN_SL < nblocks;
+                a1 += in ? (double)m[u] : 0.0;
+                a2 += in ? (double)q[u] : 0.0;
+            }
         }
     }
-    sh1[sl][cl] = a1; sh2[sl][cl] = a2;
-    __syncthreads();
+    const double s1 = fin_tree(sh, sl, cl, a1);
+    const double s2 = fin_tree(sh, sl, cl, a2);
     if (sl != 0 || c >= Hp) return;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int s = 0; s < FIN_SL; ++s) { s1 += sh1[s][cl]; s2 += sh2[s][cl]; }
     sums[c] = (float)s1;
     sums[Hp + c] = (float)s2;
     if (c < H) {

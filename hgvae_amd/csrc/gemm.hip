@@ -547,7 +547,7 @@ struct TrArgs {
     const float* g_last; const float* a_last;      // first of the last rows of G and of A (not covered by the tiles)
     int64_t ldg, lda; int n_last;                   // 1..4 such rows
     int N, K;
-    float* GW; float* gbias;
+    float* GW; int64_t ldgw; float* gbias;
 };
 
 __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
             const int k = yb * 16 * g.wk + g.wk * (lane & 15) + c;
             if (n < g.N && k < g.K) {
                 for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)g.a_last[q2 * g.lda + k];
-                g.GW[(int64_t)n * g.K + k] = (float)v;
+                g.GW[(int64_t)n * g.ldgw + k] = (float)v;
             }
         }
     }
@@ -850,12 +850,12 @@ extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) {
     return hgv_align256(sets * p.tile_elems * 4) + hgv_align256(sets * p.bias_elems * 4);
 }
 
-// GW[N,K] (row-major, ld = K) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
+// GW[N,K] (row-major, leading dimension ldgw >= K) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
 // G and A are row-major with leading dimensions >= their widths (any 4-byte aligned pointers).
 extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M,
-                           float* GW, float* gbias, void* ws, size_t ws_bytes, hipStream_t stream) {
+                           float* GW, int64_t ldgw, float* gbias, void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(M > 0 && N > 0 && K > 0, HGV_EINVAL, "gemm_tn: bad sizes");
-    HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
+    HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K && ldgw >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_tn: N=%d > 288", N);
     HGV_REQUIRE(ldg < (1 << 27) && lda < (1 << 27), HGV_EUNSUPPORTED, "gemm_tn: leading dimension too large");
     HGV_REQUIRE(ws_bytes >= hgv_gemm_tn_ws(M, N, K) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
@@ -890,7 +890,7 @@ extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, i
     r.partial = partial; r.bias_partial = bias_partial; r.sets = p.sets;
     r.wn = p.wn; r.nb = p.nb; r.wk = p.wk; r.ngrp = p.ngrp; r.kblk = p.kblk;
     r.g_last = G + Mf * ldg; r.a_last = A + Mf * lda; r.ldg = ldg; r.lda = lda; r.n_last = (int)(M - Mf);
-    r.N = N; r.K = K; r.GW = GW; r.gbias = gbias;
+    r.N = N; r.K = K; r.GW = GW; r.ldgw = ldgw; r.gbias = gbias;
     const int64_t elems = p.tile_elems + (gbias ? p.bias_elems : 0);
     hipLaunchKernelGGL(k_reduce_tn, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn");

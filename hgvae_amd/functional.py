@@ -165,14 +165,17 @@ def _gemm_nt(xa, wa, wa_t: bool, xb, wb, bias, n_out: int) -> torch.Tensor:
     return out
 
 
-def _gemm_tn(g, x, want_bias: bool):
-    """(g^T @ x  [N, K] contiguous,  column sums of g or None); g, x in the padded layout."""
+def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None):
+    """(g^T @ x  [N, K],  column sums of g or None); g, x in the padded layout.  ``out`` may be a
+    column block (unit column stride) of a wider gradient; by default a new contiguous matrix."""
     m, n, k = g.size(0), g.size(1), x.size(1)
-    gw = torch.empty(n, k, dtype=torch.float32, device=g.device)
+    gw = torch.empty(n, k, dtype=torch.float32, device=g.device) if out is None else out
+    if tuple(gw.shape) != (n, k) or gw.stride(1) != 1 or gw.stride(0) < k:
+        raise _lib.HgvError(f"weight-gradient output of shape {tuple(gw.shape)} / strides {gw.stride()} for a {n}x{k} product")
     gb = torch.empty(n, dtype=torch.float32, device=g.device) if want_bias else None
     ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
-    _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), _lib.ptr(gb),
-              ws.data_ptr(), ws.numel(), _lib.stream())
+    _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), gw.stride(0),
+              _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream())
     return gw, gb
 
 
@@ -209,6 +212,49 @@ class _DualLinear(torch.autograd.Function):
             if need[3]:
                 gwb, _ = _gemm_tn(g, xb, False)
         return gxa, gwa if need[1] else None, gxb, gwb, gb
+
+
+class _ConcatLinear(torch.autograd.Function):
+    """y = [xa | xb] @ W^T + bias for one weight W [n_out, Ka + Kb] (a decoder level fed by the
+    concatenation of the running activation and a skip tensor, gvae/gvae_skipcon.py:92-100).  The
+    concatenation is never built, and both halves of the weight gradient are written straight into
+    one [n_out, Ka + Kb] matrix."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, w, bias):
+        _lib.require_cuda(xa, xb, w)
+        ka, kb = xa.size(1), xb.size(1)
+        if w.size(1) != ka + kb:
+            raise _lib.HgvError(f"weight of shape {tuple(w.shape)} for inputs of widths {ka} + {kb}")
+        if max(w.size(0), ka, kb) > MAX_GEMM_N:
+            raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported (got {tuple(w.shape)})")
+        xa, xb = as_padded(xa), as_padded(xb)
+        y = _gemm_nt(xa, w[:, :ka], False, xb, w[:, ka:], bias, w.size(0))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xa, xb, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xa, xb, w = ctx.saved_tensors
+        ka = xa.size(1)
+        g = as_padded(g)
+        need = ctx.needs_input_grad
+        gxa = gxb = gw = gb = None
+        if need[0]:
+            gxa = _gemm_nt(g, w[:, :ka], True, None, None, None, ka)
+        if need[1]:
+            gxb = _gemm_nt(g, w[:, ka:], True, None, None, None, xb.size(1))
+        want_bias = ctx.has_bias and need[3]
+        if need[2] or want_bias:
+            gw = torch.empty_like(w, memory_format=torch.contiguous_format)
+            _, gb = _gemm_tn(g, xa, want_bias, gw[:, :ka])
+            _gemm_tn(g, xb, False, gw[:, ka:])
+        return gxa, gxb, gw if need[2] else None, gb
+
+
+def concat_linear(xa, xb, w, bias=None):
+    return _ConcatLinear.apply(xa, xb, w, bias)
 
 
 def _packed_stack(wl: torch.Tensor, wr: torch.Tensor) -> torch.Tensor:

@@ -114,13 +114,10 @@ class SkipconVAE(_VAEBase):
         return x1, x2, mean, log_std
 
     def decode(self, z, skip1, skip2):
-        h = self.hidden_channels
         d1, d2, d3 = self.decoder1, self.decoder2, self.decoder3
         h1 = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=False)
-        w2 = d2[0].weight
-        h2 = self._finish(Fn.dual_linear(h1, w2[:, :h], skip1, w2[:, h:], d2[0].bias), d2[1], d2[2], relu=False)
-        w3 = d3[0].weight
-        h3 = self._finish(Fn.dual_linear(h2, w3[:, :h], skip2, w3[:, h:], d3[0].bias), d3[1], d3[2], relu=False)
+        h2 = self._finish(Fn.concat_linear(h1, skip1, d2[0].weight, d2[0].bias), d2[1], d2[2], relu=False)
+        h3 = self._finish(Fn.concat_linear(h2, skip2, d3[0].weight, d3[0].bias), d3[1], d3[2], relu=False)
         return Fn.dual_linear(h3, d3[3].weight, None, None, d3[3].bias)
 
     def forward(self, x, edge_index, batch=None):
@@ -267,9 +264,8 @@ class CustomPoolVAE(PoolVAE):
     def decode(self, z, x1):
         zt = self.x1_transform
         x1_t = Fn.dual_linear(x1, zt.weight, None, None, zt.bias)
-        d1, zd = self.decoder1, self.out_channels
-        w = d1[0].weight
-        y = Fn.dual_linear(z, w[:, :zd], x1_t, w[:, zd:], d1[0].bias)
+        d1 = self.decoder1
+        y = Fn.concat_linear(z, x1_t, d1[0].weight, d1[0].bias)
         h = self._finish(y, d1[1], d1[2], relu=True)
         return Fn.dual_linear(h, self.decoder2[0].weight, None, None, self.decoder2[0].bias)
 

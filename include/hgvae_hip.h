@@ -172,8 +172,10 @@ int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* o
  * lda >= ceil(K/4)*4, pad columns [K, lda) finite.  Columns [N, ldc) of C are written as zeros.  N <= 288.
  * The weights are first packed into ws (hgv_gemm_nt_ws bytes); callers that reuse a weight can pack once
  * with hgv_pack_weight (hgv_pack_bytes bytes per weight) and call hgv_gemm_nt_packed.
- * hgv_gemm_tn:  GW[N,K] (contiguous) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
- * Reduction over M is split over workgroups and combined in a fixed order (reproducible). */
+ * hgv_gemm_tn:  GW[N,K] (row-major, leading dimension ldgw >= K, so that it can be a column block of a wider
+ * weight gradient) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).  G, A: row-major, any 4-byte
+ * aligned pointers, leading dimensions >= their widths.  The reduction over M is split over workgroups and
+ * combined in a fixed order (reproducible). */
 int hgv_pack_rows(int N);
 size_t hgv_pack_bytes(int N, int K);
 int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, hgv_stream_t stream);
@@ -190,7 +192,7 @@ int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W1, int64_t 
                 float* C, int64_t ldc, void* ws, size_t ws_bytes, hgv_stream_t stream);
 size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
-                float* gbias, void* ws, size_t ws_bytes, hgv_stream_t stream);
+                int64_t ldgw, float* gbias, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 #ifdef __cplusplus
 }
