@@ -1,8 +1,8 @@
 """Autograd operators over the HIP kernels (forward and hand-written backward).
 
 Every function here launches kernels from ``libhgvae_hip.so`` on the current
-stream; dense projections go through ``torch.mm`` into padded buffers.  Nothing
-falls back to a CPU or eager re-implementation.
+stream, the fp32-MFMA projections included.  Nothing falls back to a CPU or eager
+re-implementation.
 """
 from __future__ import annotations
 

@@ -29,7 +29,7 @@ def protein_like_graph(n: int, mean_degree: int, f_in: int, gen: torch.Generator
     d = torch.minimum(d, d.t())  # exactly symmetric, so every edge has its reverse
     d.fill_diagonal_(float("inf"))
     k = min(n * mean_degree, n * (n - 1))
-    cutoff = torch.kthvalue(d.flatten(), k).values
+    cutoff = torch.sort(d.flatten()).values[k - 1]   # k-th smallest distance (a device radix sort; kthvalue is ~20x slower here)
     row, col = (d <= cutoff).nonzero(as_tuple=True)
     edge_index = torch.stack([row, col])  # sorted by source; the target sort is real work
     n_atom, n_res = f_in - 10, 7
