@@ -97,6 +97,26 @@ class SkipconVAE(_VAEBase):
         self.decoder1 = nn.Sequential(nn.Linear(z, h), nn.Dropout(p), nn.BatchNorm1d(h))
         self.decoder2 = nn.Sequential(nn.Linear(2 * h, h), nn.Dropout(p), nn.BatchNorm1d(h))
         self.decoder3 = nn.Sequential(nn.Linear(2 * h, h), nn.Dropout(p), nn.BatchNorm1d(h), nn.Linear(h, in_channels))
+        self._conv1_memo = None
+
+    def _conv1(self, x, g):
+        """First convolution, computed once for the two encode passes of a step.
+
+        The reference encodes every batch twice (forward, then ``model.encode`` again for the KL
+        term, gvae/gvae_skipcon.py:166-171).  Nothing stochastic precedes the first SAGEConv, so its
+        output is the same tensor in both passes: the second pass reuses it (and the autograd node,
+        so the convolution is also differentiated once, on the summed gradient).  The memo is
+        consumed by the second call and is ignored if the input, graph, weights or grad mode changed.
+        """
+        conv = self.encoder1[0]
+        key = (x._version, x.data_ptr(), tuple(p._version for p in conv.parameters()), torch.is_grad_enabled())
+        memo = self._conv1_memo
+        if memo is not None and memo[0] is x and memo[1] is g and memo[2] == key:
+            self._conv1_memo = None
+            return memo[3]
+        y = conv(x, g)
+        self._conv1_memo = (x, g, key, y)
+        return y
 
     def _make_level2(self, h, p):
         return nn.Sequential(SAGEConv(h, h), nn.Dropout(p), nn.BatchNorm1d(h))
@@ -107,7 +127,7 @@ class SkipconVAE(_VAEBase):
     def encode(self, x, edge_index):
         g = graph_of(edge_index, x.size(0))
         x = padded_input(x)
-        x1 = self._sage_level(self.encoder1, x, g)
+        x1 = self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True)
         x2 = self._level2(x1, g)
         x3 = self._sage_level(self.encoder3, x2, g)
         mean, log_std = split_head(self.encoder3[3](x3, g), self.out_channels)
