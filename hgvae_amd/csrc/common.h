@@ -94,9 +94,15 @@ struct HgvPhilox {
     uint32_t k0, k1;
     __device__ __forceinline__ HgvPhilox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
     __device__ __forceinline__ uint4 operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
+        return rounds<10>(c0, c1, c2, c3);
+    }
+    // Philox4x32-R.  R = 7 is the smallest round count that passes BigCrush in the generator's paper;
+    // keep decisions of dropout use it (4 integer multiplies per round dominate those kernels).
+    template <int R>
+    __device__ __forceinline__ uint4 rounds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) const {
         uint32_t a = k0, b = k1;
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
+        for (int r = 0; r < R; ++r) {
             const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
             const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
             const uint32_t n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;

@@ -13,17 +13,20 @@
 // first row (no catastrophic cancellation), writes (mean_b, M2_b); a second tiny kernel
 // merges the partials with Chan's formula in fp64.  No atomics -> bitwise reproducible.
 //
-// Thread mapping: a thread owns one 4-column chunk; 256/CH row slots run side by side so
-// consecutive threads read consecutive 16-byte pieces of consecutive rows.
+// Thread mapping: a thread owns the 4-column chunks cp and cp + CP of a row (CP = half the chunks, so
+// consecutive threads still read consecutive 16-byte pieces); 256/CP row slots run side by side.
+// One Philox call yields the 8 keep decisions of a chunk pair (16 random bits per element, i.e.
+// keep probability quantised to 1/65536): the integer multiplies of the generator, not memory,
+// bounded these kernels when every 4 elements paid for a call of their own.
 #include "common.h"
 
 namespace {
 
 struct EpArgs {
     const float* y; int64_t ldy;
-    int64_t N; int H; int CH; int RPB; int64_t rows_per_block;
+    int64_t N; int H; int CH; int CP; int RPB; int64_t rows_per_block;   // CH chunks, CP chunk pairs per row
     int relu; int mode;              // mode 0: no dropout, 1: explicit mask, 2: Philox
-    float p; float scale;
+    float p; float scale; uint32_t thresh;   // Philox: keep iff 16 random bits >= thresh = round(p * 65536)
     const uint8_t* mask;             // [N, H] contiguous
     uint64_t seed, offset;
     const uint64_t* offset_dev;      // optional device word added to offset (advanced once per step under graph replay)
@@ -57,86 +60,114 @@ __device__ __forceinline__ void st4(float* base, int64_t ld, int64_t row, int c0
     }
 }
 
-// keep-multipliers (0 or scale) for the 4 columns of a chunk
-__device__ __forceinline__ float4 keep4(const EpArgs& a, int64_t row, int chunk) {
-    float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
-    const int c0 = chunk * 4;
+// keep-multipliers (0 or scale) for the two 4-column chunks (cp, cp + CP) of chunk pair cp
+__device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, float4 (&k)[2]) {
+    k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.mode == 1) {
-        const uint8_t* m = a.mask + row * a.H + c0;
-        k.x = (c0 + 0 < a.H && m[0]) ? a.scale : 0.f;
-        k.y = (c0 + 1 < a.H && m[1]) ? a.scale : 0.f;
-        k.z = (c0 + 2 < a.H && m[2]) ? a.scale : 0.f;
-        k.w = (c0 + 3 < a.H && m[3]) ? a.scale : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = (cp + h * a.CP) * 4;
+            const uint8_t* m = a.mask + row * a.H + c0;
+            k[h].x = (c0 + 0 < a.H && m[0]) ? a.scale : 0.f;
+            k[h].y = (c0 + 1 < a.H && m[1]) ? a.scale : 0.f;
+            k[h].z = (c0 + 2 < a.H && m[2]) ? a.scale : 0.f;
+            k[h].w = (c0 + 3 < a.H && m[3]) ? a.scale : 0.f;
+        }
     } else if (a.mode == 2) {
         const HgvPhilox ph(a.seed);
         const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
-        const uint4 r = ph((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)chunk << 8),
-                           (uint32_t)off, (uint32_t)(off >> 32));
-        k.x = hgv_u01(r.x) >= a.p ? a.scale : 0.f;
-        k.y = hgv_u01(r.y) >= a.p ? a.scale : 0.f;
-        k.z = hgv_u01(r.z) >= a.p ? a.scale : 0.f;
-        k.w = hgv_u01(r.w) >= a.p ? a.scale : 0.f;
+        const uint4 r = ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)cp << 8),
+                                     (uint32_t)off, (uint32_t)(off >> 32));
+        const uint32_t T = a.thresh;
+        k[0].x = (r.x & 0xffffu) >= T ? a.scale : 0.f; k[0].y = (r.x >> 16) >= T ? a.scale : 0.f;
+        k[0].z = (r.y & 0xffffu) >= T ? a.scale : 0.f; k[0].w = (r.y >> 16) >= T ? a.scale : 0.f;
+        k[1].x = (r.z & 0xffffu) >= T ? a.scale : 0.f; k[1].y = (r.z >> 16) >= T ? a.scale : 0.f;
+        k[1].z = (r.w & 0xffffu) >= T ? a.scale : 0.f; k[1].w = (r.w >> 16) >= T ? a.scale : 0.f;
     }
-    return k;
 }
 
-template <bool VEC>
-__device__ __forceinline__ float4 load_d(const EpArgs& a, int64_t row, int chunk, float4* y_out = nullptr,
+// Column offsets of the thread's two chunks; a missing second chunk (odd chunk count) aliases the
+// first one, so every load stays unconditional and in bounds - its results are simply not used.
+__device__ __forceinline__ void chunk_cols(const EpArgs& a, int cp, int (&c)[2]) {
+    c[0] = cp * 4;
+    c[1] = (cp + a.CP < a.CH ? cp + a.CP : cp) * 4;
+}
+
+// d = dropout(relu(y)) for the two chunks of pair cp in one row; yv holds the loaded y values
+__device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, const float4 (&yv)[2], float4 (&d)[2],
                                          float4* keep_out = nullptr) {
-    float4 v = ld4<VEC>(a.y, a.ldy, row, chunk * 4, a.H);
-    if (y_out) *y_out = v;
-    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (a.mode != 0) {
-        const float4 k = keep4(a, row, chunk);
-        if (keep_out) *keep_out = k;
-        v.x *= k.x; v.y *= k.y; v.z *= k.z; v.w *= k.w;
-    } else if (keep_out) {
-        *keep_out = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 k[2];
+    if (a.mode != 0) keep8(a, row, cp, k);
+    else k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float4 v = yv[h];
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.mode != 0) { v.x *= k[h].x; v.y *= k[h].y; v.z *= k[h].z; v.w *= k[h].w; }
+        if (keep_out) keep_out[h] = k[h];
+        d[h] = v;
     }
-    return v;
 }
 
 // partial layout: [block][2][Hp] = (mean_b, M2_b), Hp = CH*4
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial) {
-    __shared__ float4 sh[256];
-    __shared__ float4 sh2[256];
+    __shared__ float4 sh[512];
+    __shared__ float4 sh2[512];
     const int t = threadIdx.x;
-    const bool active = t < a.RPB * a.CH;
-    const int rsub = t / a.CH, chunk = t - rsub * a.CH;
+    const bool active = t < a.RPB * a.CP;
+    const int rsub = t / a.CP, cp = t - rsub * a.CP;
+    const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    if (active && rsub == 0) sh[chunk] = load_d<VEC>(a, r0, chunk);
+    int cc[2];
+    chunk_cols(a, cp, cc);
+    if (active && rsub == 0) {
+        float4 yv[2], d[2];
+        yv[0] = ld4<VEC>(a.y, a.ldy, r0, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, r0, cc[1], a.H);
+        apply_d2(a, r0, cp, yv, d);
+        sh[2 * cp] = d[0]; sh[2 * cp + 1] = d[1];
+    }
     __syncthreads();
-    float4 s = make_float4(0, 0, 0, 0), S1 = s, S2 = s;
+    float4 s[2], S1[2], S2[2];
+    s[0] = s[1] = S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
     if (active) {
-        s = sh[chunk];
+        s[0] = sh[2 * cp]; s[1] = sh[2 * cp + 1];
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-            const float4 d = load_d<VEC>(a, row, chunk);
-            const float tx = d.x - s.x, ty = d.y - s.y, tz = d.z - s.z, tw = d.w - s.w;
-            S1.x += tx; S1.y += ty; S1.z += tz; S1.w += tw;
-            S2.x += tx * tx; S2.y += ty * ty; S2.z += tz * tz; S2.w += tw * tw;
+            float4 yv[2], d[2];
+            yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
+            apply_d2(a, row, cp, yv, d);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float tx = d[h].x - s[h].x, ty = d[h].y - s[h].y, tz = d[h].z - s[h].z, tw = d[h].w - s[h].w;
+                S1[h].x += tx; S1[h].y += ty; S1[h].z += tz; S1[h].w += tw;
+                S2[h].x += tx * tx; S2[h].y += ty * ty; S2[h].z += tz * tz; S2[h].w += tw * tw;
+            }
         }
     }
     __syncthreads();
-    sh[t] = S1; sh2[t] = S2;
+    sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
     __syncthreads();
     if (active && rsub == 0) {
         for (int r = 1; r < a.RPB; ++r) {
-            const float4 u = sh[r * a.CH + chunk], w = sh2[r * a.CH + chunk];
-            S1.x += u.x; S1.y += u.y; S1.z += u.z; S1.w += u.w;
-            S2.x += w.x; S2.y += w.y; S2.z += w.z; S2.w += w.w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
+                S1[h].x += u.x; S1[h].y += u.y; S1[h].z += u.z; S1[h].w += u.w;
+                S2[h].x += w.x; S2[h].y += w.y; S2[h].z += w.z; S2[h].w += w.w;
+            }
         }
         const float n = (float)(r1 - r0);
-        float4 m, q;
-        m.x = s.x + S1.x / n; m.y = s.y + S1.y / n; m.z = s.z + S1.z / n; m.w = s.w + S1.w / n;
-        q.x = S2.x - S1.x * S1.x / n; q.y = S2.y - S1.y * S1.y / n;
-        q.z = S2.z - S1.z * S1.z / n; q.w = S2.w - S1.w * S1.w / n;
         const int Hp = a.CH * 4;
-        float* pm = partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + chunk * 4;
-        float* pq = partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + chunk * 4;
-        *reinterpret_cast<float4*>(pm) = m;
-        *reinterpret_cast<float4*>(pq) = q;
+        for (int h = 0; h < nh; ++h) {
+            float4 m, q;
+            m.x = s[h].x + S1[h].x / n; m.y = s[h].y + S1[h].y / n; m.z = s[h].z + S1[h].z / n; m.w = s[h].w + S1[h].w / n;
+            q.x = S2[h].x - S1[h].x * S1[h].x / n; q.y = S2[h].y - S1[h].y * S1[h].y / n;
+            q.z = S2[h].z - S1[h].z * S1[h].z / n; q.w = S2[h].w - S1[h].w * S1[h].w / n;
+            const int c0 = (cp + h * a.CP) * 4;
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = m;
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = q;
+        }
     }
 }
 
@@ -235,23 +266,38 @@ __device__ __forceinline__ float4 ldcol4(const float* p, int c0, int H, float fi
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs n) {
     const int t = threadIdx.x;
-    if (t >= a.RPB * a.CH) return;
-    const int rsub = t / a.CH, chunk = t - rsub * a.CH, c0 = chunk * 4;
+    if (t >= a.RPB * a.CP) return;
+    const int rsub = t / a.CP, cp = t - rsub * a.CP;
+    const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    const float4 mu = ldcol4(n.mean, c0, a.H, 0.f);
-    float4 rs = ldcol4(n.rstd_or_var, c0, a.H, 1.f);
-    if (n.rstd_is_var) {
-        rs.x = 1.f / sqrtf(rs.x + n.eps); rs.y = 1.f / sqrtf(rs.y + n.eps);
-        rs.z = 1.f / sqrtf(rs.z + n.eps); rs.w = 1.f / sqrtf(rs.w + n.eps);
+    float4 mu[2], rs[2], ga[2], be[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c0 = (cp + h * a.CP) * 4;
+        mu[h] = ldcol4(n.mean, c0, a.H, 0.f);
+        rs[h] = ldcol4(n.rstd_or_var, c0, a.H, 1.f);
+        if (n.rstd_is_var) {
+            rs[h].x = 1.f / sqrtf(rs[h].x + n.eps); rs[h].y = 1.f / sqrtf(rs[h].y + n.eps);
+            rs[h].z = 1.f / sqrtf(rs[h].z + n.eps); rs[h].w = 1.f / sqrtf(rs[h].w + n.eps);
+        }
+        ga[h] = ldcol4(n.gamma, c0, a.H, 1.f); be[h] = ldcol4(n.beta, c0, a.H, 0.f);
     }
-    const float4 ga = ldcol4(n.gamma, c0, a.H, 1.f), be = ldcol4(n.beta, c0, a.H, 0.f);
+    int cc[2];
+    chunk_cols(a, cp, cc);
     for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-        const float4 d = load_d<VEC>(a, row, chunk);
-        float4 o;
-        o.x = (d.x - mu.x) * rs.x * ga.x + be.x; o.y = (d.y - mu.y) * rs.y * ga.y + be.y;
-        o.z = (d.z - mu.z) * rs.z * ga.z + be.z; o.w = (d.w - mu.w) * rs.w * ga.w + be.w;
-        st4<VEC>(n.out, n.ldo, row, c0, a.H, o);
+        float4 yv[2], d[2];
+        yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
+        apply_d2(a, row, cp, yv, d);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h < nh) {
+                float4 o;
+                o.x = (d[h].x - mu[h].x) * rs[h].x * ga[h].x + be[h].x; o.y = (d[h].y - mu[h].y) * rs[h].y * ga[h].y + be[h].y;
+                o.z = (d[h].z - mu[h].z) * rs[h].z * ga[h].z + be[h].z; o.w = (d[h].w - mu[h].w) * rs[h].w * ga[h].w + be[h].w;
+                st4<VEC>(n.out, n.ldo, row, (cp + h * a.CP) * 4, a.H, o);
+            }
+        }
     }
 }
 
@@ -266,35 +312,58 @@ struct BwdArgs {
 // partial layout: [block][2][Hp] = (sum g, sum g*xhat)
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdArgs b, float* __restrict__ partial) {
-    __shared__ float4 sh[256];
-    __shared__ float4 sh2[256];
+    __shared__ float4 sh[512];
+    __shared__ float4 sh2[512];
     const int t = threadIdx.x;
-    const bool active = t < a.RPB * a.CH;
-    const int rsub = t / a.CH, chunk = t - rsub * a.CH, c0 = chunk * 4;
+    const bool active = t < a.RPB * a.CP;
+    const int rsub = t / a.CP, cp = t - rsub * a.CP;
+    const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    float4 S1 = make_float4(0, 0, 0, 0), S2 = S1;
+    float4 S1[2], S2[2];
+    S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
     if (active) {
-        const float4 mu = ldcol4(b.mean, c0, a.H, 0.f), rs = ldcol4(b.rstd, c0, a.H, 0.f);
+        float4 mu[2], rs[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            mu[h] = ldcol4(b.mean, (cp + h * a.CP) * 4, a.H, 0.f);
+            rs[h] = ldcol4(b.rstd, (cp + h * a.CP) * 4, a.H, 0.f);
+        }
+        int cc[2];
+        chunk_cols(a, cp, cc);
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-            const float4 d = load_d<VEC>(a, row, chunk);
-            const float4 g = ld4<VEC>(b.g, b.ldg, row, c0, a.H);
-            S1.x += g.x; S1.y += g.y; S1.z += g.z; S1.w += g.w;
-            S2.x += g.x * ((d.x - mu.x) * rs.x); S2.y += g.y * ((d.y - mu.y) * rs.y);
-            S2.z += g.z * ((d.z - mu.z) * rs.z); S2.w += g.w * ((d.w - mu.w) * rs.w);
+            float4 yv[2], gv[2], d[2];
+            yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
+            gv[0] = ld4<VEC>(b.g, b.ldg, row, cc[0], a.H); gv[1] = ld4<VEC>(b.g, b.ldg, row, cc[1], a.H);
+            apply_d2(a, row, cp, yv, d);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                {
+                    const float4 g = gv[h];
+                    S1[h].x += g.x; S1[h].y += g.y; S1[h].z += g.z; S1[h].w += g.w;
+                    S2[h].x += g.x * ((d[h].x - mu[h].x) * rs[h].x); S2[h].y += g.y * ((d[h].y - mu[h].y) * rs[h].y);
+                    S2[h].z += g.z * ((d[h].z - mu[h].z) * rs[h].z); S2[h].w += g.w * ((d[h].w - mu[h].w) * rs[h].w);
+                }
+            }
         }
     }
-    sh[t] = S1; sh2[t] = S2;
+    sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
     __syncthreads();
     if (active && rsub == 0) {
         for (int r = 1; r < a.RPB; ++r) {
-            const float4 u = sh[r * a.CH + chunk], w = sh2[r * a.CH + chunk];
-            S1.x += u.x; S1.y += u.y; S1.z += u.z; S1.w += u.w;
-            S2.x += w.x; S2.y += w.y; S2.z += w.z; S2.w += w.w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
+                S1[h].x += u.x; S1[h].y += u.y; S1[h].z += u.z; S1[h].w += u.w;
+                S2[h].x += w.x; S2[h].y += w.y; S2[h].z += w.z; S2[h].w += w.w;
+            }
         }
         const int Hp = a.CH * 4;
-        *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = S1;
-        *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = S2;
+        for (int h = 0; h < nh; ++h) {
+            const int c0 = (cp + h * a.CP) * 4;
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = S1[h];
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = S2[h];
+        }
     }
 }
 
@@ -336,32 +405,50 @@ __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restric
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ep_bwd_apply(const EpArgs a, const BwdArgs b) {
     const int t = threadIdx.x;
-    if (t >= a.RPB * a.CH) return;
-    const int rsub = t / a.CH, chunk = t - rsub * a.CH, c0 = chunk * 4;
+    if (t >= a.RPB * a.CP) return;
+    const int rsub = t / a.CP, cp = t - rsub * a.CP;
+    const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
     const int Hp = a.CH * 4;
     const float invn = 1.f / (float)a.N;
-    const float4 mu = ldcol4(b.mean, c0, a.H, 0.f), rs = ldcol4(b.rstd, c0, a.H, 0.f);
-    const float4 ga = ldcol4(b.gamma, c0, a.H, 1.f);
-    const float4 sg = *reinterpret_cast<const float4*>(b.sums + c0);
-    const float4 sgx = *reinterpret_cast<const float4*>(b.sums + Hp + c0);
-    for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-        float4 y, k;
-        const float4 d = load_d<VEC>(a, row, chunk, &y, &k);
-        const float4 g = ld4<VEC>(b.g, b.ldg, row, c0, a.H);
-        float4 o;
-#define HGV_EP_BWD(f)                                                                              \
-        {                                                                                          \
-            const float xh = (d.f - mu.f) * rs.f;                                                  \
-            float dd = ga.f * rs.f * (g.f - sg.f * invn - xh * (sgx.f * invn));                   \
-            dd *= k.f;                                                                             \
-            if (a.relu && !(y.f > 0.f)) dd = 0.f;                                                  \
-            o.f = dd;                                                                              \
+    float4 mu[2], rs[2], ga[2], sg[2], sgx[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c0 = (cp + h * a.CP) * 4;
+        mu[h] = ldcol4(b.mean, c0, a.H, 0.f); rs[h] = ldcol4(b.rstd, c0, a.H, 0.f); ga[h] = ldcol4(b.gamma, c0, a.H, 1.f);
+        sg[h] = sgx[h] = make_float4(0, 0, 0, 0);
+        if (h < nh) {
+            sg[h] = *reinterpret_cast<const float4*>(b.sums + c0);
+            sgx[h] = *reinterpret_cast<const float4*>(b.sums + Hp + c0);
         }
-        HGV_EP_BWD(x) HGV_EP_BWD(y) HGV_EP_BWD(z) HGV_EP_BWD(w)
+    }
+    int cc[2];
+    chunk_cols(a, cp, cc);
+    for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
+        float4 d[2], y[2], k[2], gv[2];
+        y[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); y[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
+        gv[0] = ld4<VEC>(b.g, b.ldg, row, cc[0], a.H); gv[1] = ld4<VEC>(b.g, b.ldg, row, cc[1], a.H);
+        apply_d2(a, row, cp, y, d, k);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h < nh) {
+                const int c0 = cc[h];
+                const float4 g = gv[h];
+                float4 o;
+#define HGV_EP_BWD(f)                                                                              \
+                {                                                                                  \
+                    const float xh = (d[h].f - mu[h].f) * rs[h].f;                                 \
+                    float dd = ga[h].f * rs[h].f * (g.f - sg[h].f * invn - xh * (sgx[h].f * invn)); \
+                    dd *= k[h].f;                                                                  \
+                    if (a.relu && !(y[h].f > 0.f)) dd = 0.f;                                       \
+                    o.f = dd;                                                                      \
+                }
+                HGV_EP_BWD(x) HGV_EP_BWD(y) HGV_EP_BWD(z) HGV_EP_BWD(w)
 #undef HGV_EP_BWD
-        st4<VEC>(b.dy, b.lddy, row, c0, a.H, o);
+                st4<VEC>(b.dy, b.lddy, row, c0, a.H, o);
+            }
+        }
     }
 }
 
@@ -369,16 +456,17 @@ bool vec4_ok(const float* p, int64_t ld, int Hp) { return p == nullptr || (hgv_a
 
 int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int* nblocks) {
-    HGV_REQUIRE(N > 0 && H > 0 && H <= 1024, HGV_EINVAL, "bn_act: need N > 0 and 0 < H <= 1024 (N=%lld H=%d)", (long long)N, H);
+    HGV_REQUIRE(N > 0 && H > 0 && H <= 2048, HGV_EINVAL, "bn_act: need N > 0 and 0 < H <= 2048 (N=%lld H=%d)", (long long)N, H);
     HGV_REQUIRE(y && ldy >= H, HGV_EINVAL, "bn_act: bad input buffer");
     HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "bn_act: dropout p=%f outside [0,1)", p);
-    a.y = y; a.ldy = ldy; a.N = N; a.H = H; a.CH = (H + 3) / 4; a.RPB = 256 / a.CH;
+    a.y = y; a.ldy = ldy; a.N = N; a.H = H; a.CH = (H + 3) / 4; a.CP = (a.CH + 1) / 2; a.RPB = 256 / a.CP;
     a.relu = relu; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
+    a.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
     a.mask = mask; a.seed = seed; a.offset = offset; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
-    // row ranges: enough workgroups to fill the chip (8 per CU), at least 8 rows per thread
-    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 8);
-    if (nb > 2048) nb = 2048;
+    // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread
+    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 4);
+    if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     a.rows_per_block = hgv_cdiv(N, nb);
     *nblocks = (int)hgv_cdiv(N, a.rows_per_block);
@@ -394,8 +482,8 @@ extern "C" size_t hgv_bn_act_ws(int64_t N, int H) {
 }
 
 // Training-mode forward.  mask: explicit keep mask [N,H] (uint8, contiguous) or null; with
-// p > 0 and no mask the keep decisions come from Philox4x32-10 keyed by (seed, offset, row,
-// chunk) and the backward pass regenerates them from the same (seed, offset).
+// p > 0 and no mask the keep decisions come from Philox4x32 keyed by (seed, offset, row, chunk pair),
+// 16 random bits per element, and the backward pass regenerates them from the same (seed, offset).
 extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma,
                               const float* beta, float eps,

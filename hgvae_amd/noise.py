@@ -1,7 +1,7 @@
 """Where dropout masks and normal draws come from.
 
 Default: nothing is materialised - kernels derive every keep decision / normal draw
-from Philox4x32-10 keyed by ``(seed, offset)``; the offset advances once per stochastic
+from Philox4x32 (7 rounds for dropout bits, 10 for normal draws) keyed by ``(seed, offset)``; the offset advances once per stochastic
 layer call so that forward and backward regenerate identical noise.
 
 For parity tests an explicit :class:`NoiseTape` replays pre-drawn tensors in call order

@@ -79,7 +79,7 @@ int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, c
 /* ---- fused (ReLU) -> Dropout -> BatchNorm1d over nodes: gvae/gvae_skipcon.py:105-107,
  *      110-112,115-117,124,130,136 ----------------------------------------------------------
  * y is the pre-activation [N, H].  Dropout keep mask: explicit uint8 [N,H] (contiguous), or
- * Philox4x32-10 keyed by (seed, offset) when mask is null and p > 0; offset_dev (nullable) is a device
+ * Philox4x32-7 (16 random bits per element) keyed by (seed, offset) when mask is null and p > 0; offset_dev (nullable) is a device
  * word added to offset, so a captured graph can draw fresh noise on every replay.  Biased batch variance
  * for normalisation, unbiased for the running update (torch.nn.BatchNorm1d semantics). */
 size_t hgv_bn_act_ws(int64_t N, int H);
