@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one captured HIP graph (per-launch event timing is then taken "
                          "from a short eager pass after the timed region)")
-    ap.add_argument("--cpu-sample-graphs", type=int, default=4)
+    ap.add_argument("--cpu-sample-graphs", type=int, default=8)
     args = ap.parse_args()
 
     import torch.distributed as dist

@@ -452,3 +452,40 @@ def test_dual_linear_forward_backward(shape):
     if n % 4:
         base = out.as_strided((m, (n + 3) // 4 * 4), (out.stride(0), 1))
         assert float(base[:, n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(160_984, 138, 138, 138), (160_984, 105, 105, 138), (131_072 + 7, 138, None, 56),
+                                   (70_001, 276, None, 138)])
+def test_projection_kernels_at_benchmark_rows(shape):
+    """Row counts of the benchmark shard: every wave of the resident-weight kernel streams several
+    row tiles (the load ring runs across tile boundaries) and the weight-gradient kernel splits the
+    rows over ~680 slices plus the 1-4 leftover rows.  Checked against an fp64 product on the device
+    (rocBLAS dgemm: an independent implementation) on the full output."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import new_padded
+    m, k1, k2, n = shape
+    gen = torch.Generator(device=dev()).manual_seed(m + n)
+
+    def rnd(rows, cols):
+        t = new_padded(rows, cols, dev())
+        t.copy_(torch.randn(rows, cols, generator=gen, device=dev()))
+        return t
+
+    xa, xb = rnd(m, k1), (rnd(m, k2) if k2 else None)
+    w = torch.randn(n, k1 + (k2 or 0), generator=gen, device=dev())
+    bias = torch.randn(n, generator=gen, device=dev())
+    g = rnd(m, n)
+    y = Fn._gemm_nt(xa, w[:, :k1], False, xb, w[:, k1:] if k2 else None, bias, n)
+    ref = xa.double() @ w[:, :k1].double().t() + bias.double()
+    if k2:
+        ref = ref + xb.double() @ w[:, k1:].double().t()
+    scale = float(ref.abs().max())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale * (k1 + (k2 or 0)) ** 0.5
+    gx = Fn._gemm_nt(g, w[:, :k1], True, None, None, None, k1)           # grad-input product
+    refx = g.double() @ w[:, :k1].double()
+    assert float((gx.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max()) * n ** 0.5
+    gw, gb = Fn._gemm_tn(g, xa, True)
+    refw, refb = g.double().t() @ xa.double(), g.double().sum(0)
+    # M-long fp32 accumulations in slices, fp64 across slices: error ~ 1e-7 * sqrt(rows per slice) * |terms|
+    assert float((gw.double() - refw).abs().max()) <= 2e-6 * float(refw.abs().max()) + 1e-7 * m ** 0.5 * 4
+    assert float((gb.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
