@@ -123,32 +123,18 @@ class _WeightedAggregate(torch.autograd.Function):
 MAX_GEMM_N = 288
 
 
-_pack_cache: "dict[tuple, tuple]" = {}
-
-
 def _packed(w: torch.Tensor, transposed: bool) -> torch.Tensor:
-    """Packed image of a weight (or of its transpose) for the NT kernel.
+    """Packed image of a weight (or of its transpose) for the NT kernel, built at every use.
 
-    Cached per (base tensor object, view geometry) and refreshed when the tensor's version
-    changes, so a weight used by both encode passes (and again in backward) is packed once per
-    optimizer step into a buffer that is reused across steps.
+    The image is not cached across calls: ``Tensor._version`` is the only cheap change signal and it
+    misses real updates (``torch.optim.Adam(fused=True)`` and writes through ``.data`` leave it
+    untouched), and a stale image silently trains against old weights.  Packing is one small launch
+    (<= 161 KB written); the buffer comes from the caching allocator, so it is recycled in stream order.
     """
-    import weakref
-    base = w._base if w._base is not None else w
-    key = (id(base), w.storage_offset(), tuple(w.stride()), tuple(w.shape), transposed, w.device.index)
-    hit = _pack_cache.get(key)
-    version = base._version
-    if hit is not None and hit[0]() is base:
-        if hit[1] == (version, w.data_ptr()):
-            return hit[2]
-        buf = hit[2]
-    else:
-        n, k = (w.size(1), w.size(0)) if transposed else (w.size(0), w.size(1))
-        buf = torch.empty(_lib.load().hgv_pack_bytes(n, k) // 4, dtype=torch.float32, device=w.device)
     n, k = (w.size(1), w.size(0)) if transposed else (w.size(0), w.size(1))
     sn, sk = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+    buf = torch.empty(_lib.load().hgv_pack_bytes(n, k) // 4, dtype=torch.float32, device=w.device)
     _lib.call("hgv_pack_weight", w.data_ptr(), sn, sk, n, k, buf.data_ptr(), _lib.stream())
-    _pack_cache[key] = (weakref.ref(base, lambda _r, kk=key: _pack_cache.pop(kk, None)), (version, w.data_ptr()), buf)
     return buf
 
 
@@ -258,22 +244,12 @@ def concat_linear(xa, xb, w, bias=None):
 
 
 def _packed_stack(wl: torch.Tensor, wr: torch.Tensor) -> torch.Tensor:
-    """Packed image of [wl ; wr] stacked along the output dimension (both [n_out, K])."""
-    import weakref
-    key = ("stack", id(wl), id(wr), tuple(wl.shape), wl.device.index)
-    sig = (wl._version, wr._version, wl.data_ptr(), wr.data_ptr())
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0]() is wl and hit[1] == sig:
-        return hit[2]
+    """Packed image of [wl ; wr] stacked along the output dimension (both [n_out, K]); built at every use."""
     n, k = wl.size(0), wl.size(1)
-    if hit is not None and hit[0]() is wl:
-        buf = hit[2]
-    else:
-        buf = torch.zeros(_lib.load().hgv_pack_bytes(2 * n, k) // 4, dtype=torch.float32, device=wl.device)
+    buf = torch.zeros(_lib.load().hgv_pack_bytes(2 * n, k) // 4, dtype=torch.float32, device=wl.device)
     for w, off in ((wl, 0), (wr, n)):
         _lib.call("hgv_pack_weight_rows", w.data_ptr(), w.stride(0), w.stride(1), n, k, buf.data_ptr(), off,
                   2 * n, _lib.stream())
-    _pack_cache[key] = (weakref.ref(wl, lambda _r, kk=key: _pack_cache.pop(kk, None)), sig, buf)
     return buf
 
 

@@ -194,6 +194,19 @@ size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
                 int64_t ldgw, float* gbias, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
+/* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
+ *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------
+ * hgv_adam_step: torch's Adam arithmetic (bias-corrected, eps added after the sqrt(v)/sqrt(1-b2^t) division,
+ * L2 weight decay folded into the gradient) on n contiguous floats; step counts from 1; step_dev (nullable device
+ * int64) overrides step so that a captured graph can advance it on the device; gscale_dev (nullable device float)
+ * multiplies the gradient first (the clip coefficient).
+ * hgv_grad_norm_clip: norm_out[0] = ||g||_2, scale_out[0] = min(1, max_norm / (norm + 1e-6)). */
+int hgv_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, const int64_t* step_dev, const float* gscale_dev, hgv_stream_t stream);
+size_t hgv_grad_norm_ws(void);
+int hgv_grad_norm_clip(const float* g, int64_t n, float max_norm, float* norm_out, float* scale_out, void* ws,
+                       size_t ws_bytes, hgv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

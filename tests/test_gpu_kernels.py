@@ -489,3 +489,50 @@ def test_projection_kernels_at_benchmark_rows(shape):
     # M-long fp32 accumulations in slices, fp64 across slices: error ~ 1e-7 * sqrt(rows per slice) * |terms|
     assert float((gw.double() - refw).abs().max()) <= 2e-6 * float(refw.abs().max()) + 1e-7 * m ** 0.5 * 4
     assert float((gb.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
+
+
+# ------------------------------------------------------------------ flat Adam / gradient clipping
+@pytest.mark.parametrize("cfg", [dict(), dict(weight_decay=0.01), dict(max_grad_norm=1.0), dict(capturable=True)])
+def test_flat_adam_matches_torch_adam(cfg):
+    """Same parameters, same gradients, 6 steps: FlatAdam (one HIP launch over the flat buffers) against
+    torch.optim.Adam (+ clip_grad_norm_) on the CPU in fp32 (autoencoder/vae_custom_pool.py:228-229)."""
+    from hgvae_amd.optim import FlatAdam
+    gen = torch.Generator().manual_seed(7)
+    shapes = [(138, 105), (138,), (56, 138), (1,), (28, 17, 3)]
+    ref = [torch.nn.Parameter(torch.randn(*s_, generator=gen)) for s_ in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(dev())) for p in ref]
+    clip = cfg.get("max_grad_norm")
+    ropt = torch.optim.Adam(ref, lr=3e-3, weight_decay=cfg.get("weight_decay", 0.0))
+    mopt = FlatAdam(mine, lr=3e-3, **cfg)
+    for step in range(6):
+        grads = [torch.randn(*s_, generator=gen) * (10.0 if step % 2 else 0.1) for s_ in shapes]
+        mopt.zero_grad()
+        for p, q, g in zip(ref, mine, grads):
+            p.grad = g.clone()
+            q.grad.add_(g.to(dev()))          # gradients accumulate into the bucket views, as autograd does
+        if clip is not None:
+            want_norm = torch.nn.utils.clip_grad_norm_(ref, clip)
+        ropt.step()
+        mopt.step()
+        if clip is not None:
+            close(mopt.last_grad_norm, want_norm, 1e-6)
+        for p, q in zip(ref, mine):
+            close(q.detach(), p.detach(), 2e-6)
+    sd = mopt.state_dict()
+    assert sd["step"] == 6 and sd["exp_avg"].numel() == sum(p.numel() for p in ref)
+
+
+def test_flat_adam_invalidates_packed_weights():
+    """The update writes through raw pointers; the projection's packed-weight cache must still see it."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.optim import FlatAdam
+    gen = torch.Generator().manual_seed(3)
+    w = torch.nn.Parameter(torch.randn(12, 20, generator=gen).to(dev()))
+    x = torch.randn(33, 20, generator=gen).to(dev())
+    opt = FlatAdam([w], lr=0.5)
+    y0 = Fn.dual_linear(x, w)
+    y0.sum().backward()
+    opt.step()
+    y1 = Fn.dual_linear(x, w).detach()
+    close(y1, x.double().cpu() @ w.detach().double().cpu().t(), 2e-6)
+    assert float((y1 - y0.detach()).abs().max()) > 1e-2

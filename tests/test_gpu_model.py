@@ -309,3 +309,44 @@ def test_graphed_train_step_replays_with_fresh_noise_and_learns():
             assert all(l == l for l in trace)
             # medians: robust to the occasional exp(log_std) spike of an untrained VAE
             assert sorted(trace[-30:])[15] < sorted(trace[:30])[15]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [True, False])
+def test_training_with_torch_adam_tracks_flat_adam(fused):
+    """Weights updated by torch.optim.Adam - including fused=True, which does not bump Tensor._version -
+    must be seen by the next forward pass: five steps with torch's optimizer and five with FlatAdam from the
+    same initial weights and noise streams give the same loss curve (packed projection weights are rebuilt
+    at every use, never cached on a version counter)."""
+    import hgvae_amd
+    from hgvae_amd import synthetic
+    from hgvae_amd.distributed import FlatGradBucket
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.vae import SkipconVAE, train_step_loss
+    dev = torch.device("cuda:0")
+    batch = synthetic.path_graph_batch([138] * 8, 60, seed=5, device=dev)
+
+    def run(kind):
+        torch.manual_seed(0)
+        hgvae_amd.manual_seed(99)
+        model = SkipconVAE(60, 138, 28).to(dev).train()
+        if kind == "flat":
+            opt = FlatAdam(model.parameters(), lr=1e-2)
+            bucket = opt.bucket
+        else:
+            opt = torch.optim.Adam(model.parameters(), lr=1e-2, fused=fused)
+            bucket = FlatGradBucket(model.parameters())
+        losses = []
+        for _ in range(5):
+            bucket.zero()
+            loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+            loss.backward()
+            bucket.all_reduce_mean()
+            opt.step()
+            losses.append(float(loss))
+        return losses
+
+    a, b = run("flat"), run("torch")
+    assert a[-1] < a[0]                       # it trains
+    for x, y in zip(a, b):
+        assert abs(x - y) <= 2e-4 * abs(x), (a, b)

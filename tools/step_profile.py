@@ -18,7 +18,7 @@ def short(name):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    adam = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"]]
+    adam = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r["Kernel_Name"] or "k_adam" in r["Kernel_Name"]]
     # Adam uses several multi_tensor launches per step; take boundaries where the gap in index is large
     bounds = [adam[0]] + [b for a, b in zip(adam, adam[1:]) if b - a > 20]
     lo, hi = bounds[-2], bounds[-1]
