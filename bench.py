@@ -148,7 +148,8 @@ def main():
     def step():
         bucket.zero()
         loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
-        loss.backward()
+        with Fn.direct_weight_grads():      # weight gradients are added into the bucket views by the kernels
+            loss.backward()
         bucket.all_reduce_mean()
         opt.step()
         return loss

@@ -548,6 +548,7 @@ struct TrArgs {
     int64_t ldg, lda; int n_last;                   // 1..4 such rows
     int N, K;
     float* GW; int64_t ldgw; float* gbias;
+    int accumulate;                                 // add to GW / gbias instead of overwriting them
 };
 
 __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
             const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (rem & 15) + r;
             if (n < g.N) {
                 for (int q = 0; q < g.n_last; ++q) v += (double)g.g_last[q * g.ldg + n];
-                g.gbias[n] = (float)v;
+                g.gbias[n] = g.accumulate ? g.gbias[n] + (float)v : (float)v;
             }
         } else {
             const int per_tile = tn * g.wk * 256;
@@ -596,7 +597,8 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
             const int k = yb * 16 * g.wk + g.wk * (lane & 15) + c;
             if (n < g.N && k < g.K) {
                 for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)g.a_last[q2 * g.lda + k];
-                g.GW[(int64_t)n * g.ldgw + k] = (float)v;
+                float* dst = g.GW + (int64_t)n * g.ldgw + k;
+                *dst = g.accumulate ? *dst + (float)v : (float)v;
             }
         }
     }
@@ -850,10 +852,12 @@ extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) {
     return hgv_align256(sets * p.tile_elems * 4) + hgv_align256(sets * p.bias_elems * 4);
 }
 
-// GW[N,K] (row-major, leading dimension ldgw >= K) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).
+// GW[N,K] (row-major, leading dimension ldgw >= K) (+)= G[M,N]^T A[M,K];  gbias[N] (+)= column sums of G (nullable).
+// accumulate != 0 adds to GW / gbias (gradient accumulation into an existing .grad buffer) instead of overwriting.
 // G and A are row-major with leading dimensions >= their widths (any 4-byte aligned pointers).
 extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M,
-                           float* GW, int64_t ldgw, float* gbias, void* ws, size_t ws_bytes, hipStream_t stream) {
+                           float* GW, int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes,
+                           hipStream_t stream) {
     HGV_REQUIRE(M > 0 && N > 0 && K > 0, HGV_EINVAL, "gemm_tn: bad sizes");
     HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K && ldgw >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_tn: N=%d > 288", N);
@@ -890,7 +894,7 @@ extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, i
     r.partial = partial; r.bias_partial = bias_partial; r.sets = p.sets;
     r.wn = p.wn; r.nb = p.nb; r.wk = p.wk; r.ngrp = p.ngrp; r.kblk = p.kblk;
     r.g_last = G + Mf * ldg; r.a_last = A + Mf * lda; r.ldg = ldg; r.lda = lda; r.n_last = (int)(M - Mf);
-    r.N = N; r.K = K; r.GW = GW; r.ldgw = ldgw; r.gbias = gbias;
+    r.N = N; r.K = K; r.GW = GW; r.ldgw = ldgw; r.gbias = gbias; r.accumulate = accumulate;
     const int64_t elems = p.tile_elems + (gbias ? p.bias_elems : 0);
     hipLaunchKernelGGL(k_reduce_tn, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn");

@@ -6,6 +6,7 @@ re-implementation.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Optional
 
 import torch
@@ -151,17 +152,62 @@ def _gemm_nt(xa, wa, wa_t: bool, xb, wb, bias, n_out: int) -> torch.Tensor:
     return out
 
 
-def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None):
+_direct_grads = False
+
+
+@contextlib.contextmanager
+def direct_weight_grads(enabled: bool = True):
+    """Inside this context the projection operators ADD weight / bias gradients straight into existing
+    ``param.grad`` buffers (e.g. the views of a :class:`FlatGradBucket`) from the reduction kernel and
+    return ``None`` for them to autograd, instead of returning a fresh tensor that autograd then adds
+    with one small kernel per parameter use.  Only leaf parameters with a preallocated contiguous
+    fp32 ``.grad`` of the right shape take the shortcut; everything else keeps the normal path.  Do
+    not combine with ``torch.autograd.grad`` or gradient hooks on those parameters."""
+    global _direct_grads
+    prev, _direct_grads = _direct_grads, bool(enabled)
+    try:
+        yield
+    finally:
+        _direct_grads = prev
+
+
+def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """``p.grad`` when gradients may be accumulated into it in place, else None."""
+    if not _direct_grads or p is None or not p.is_leaf or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or g.device != p.device:
+        return None
+    return g
+
+
+def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
+             accumulate: bool = False):
     """(g^T @ x  [N, K],  column sums of g or None); g, x in the padded layout.  ``out`` may be a
-    column block (unit column stride) of a wider gradient; by default a new contiguous matrix."""
+    column block (unit column stride) of a wider gradient; by default a new contiguous matrix.
+    With ``accumulate`` the results are added to ``out`` / ``bias_out`` instead of overwriting them."""
     m, n, k = g.size(0), g.size(1), x.size(1)
     gw = torch.empty(n, k, dtype=torch.float32, device=g.device) if out is None else out
     if tuple(gw.shape) != (n, k) or gw.stride(1) != 1 or gw.stride(0) < k:
         raise _lib.HgvError(f"weight-gradient output of shape {tuple(gw.shape)} / strides {gw.stride()} for a {n}x{k} product")
-    gb = torch.empty(n, dtype=torch.float32, device=g.device) if want_bias else None
+    if accumulate and (out is None or (want_bias and bias_out is None)):
+        raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
+    gb = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
     ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
     _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), gw.stride(0),
-              _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream())
+              _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+    return gw, gb
+
+
+def _weight_grad(g, x, w, bias=None, want_bias: bool = False):
+    """Weight (and bias) gradient of y = x @ w^T + bias: (gw, gb) for autograd, with None in place of a
+    gradient that was added straight into the parameter's ``.grad`` buffer."""
+    wbuf = _grad_buffer(w)
+    bbuf = _grad_buffer(bias) if want_bias else None
+    if wbuf is not None and (not want_bias or bbuf is not None):
+        _gemm_tn(g, x, want_bias, wbuf, bbuf, accumulate=True)
+        return None, None
+    gw, gb = _gemm_tn(g, x, want_bias)
     return gw, gb
 
 
@@ -178,26 +224,28 @@ class _DualLinear(torch.autograd.Function):
         xb = as_padded(xb) if xb is not None else None
         y = _gemm_nt(xa, wa, False, xb, wb, bias, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
-        ctx.save_for_backward(xa, wa, xb, wb)
+        ctx.save_for_backward(xa, wa, xb, wb, bias)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        xa, wa, xb, wb = ctx.saved_tensors
+        xa, wa, xb, wb, bias = ctx.saved_tensors
         g = as_padded(g)
         need = ctx.needs_input_grad
         gxa = gwa = gxb = gwb = gb = None
         want_bias = ctx.has_bias and need[4]
         if need[0]:
             gxa = _gemm_nt(g, wa, True, None, None, None, wa.size(1))
-        if need[1] or want_bias:
-            gwa, gb = _gemm_tn(g, xa, want_bias)
+        if need[1]:
+            gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
+        elif want_bias:
+            _, gb = _gemm_tn(g, xa, True)
         if ctx.has_b:
             if need[2]:
                 gxb = _gemm_nt(g, wb, True, None, None, None, wb.size(1))
             if need[3]:
-                gwb, _ = _gemm_tn(g, xb, False)
-        return gxa, gwa if need[1] else None, gxb, gwb, gb
+                gwb, _ = _weight_grad(g, xb, wb)
+        return gxa, gwa, gxb, gwb, gb
 
 
 class _ConcatLinear(torch.autograd.Function):
@@ -217,12 +265,12 @@ class _ConcatLinear(torch.autograd.Function):
         xa, xb = as_padded(xa), as_padded(xb)
         y = _gemm_nt(xa, w[:, :ka], False, xb, w[:, ka:], bias, w.size(0))
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(xa, xb, w)
+        ctx.save_for_backward(xa, xb, w, bias)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        xa, xb, w = ctx.saved_tensors
+        xa, xb, w, bias = ctx.saved_tensors
         ka = xa.size(1)
         g = as_padded(g)
         need = ctx.needs_input_grad
@@ -233,10 +281,18 @@ class _ConcatLinear(torch.autograd.Function):
             gxb = _gemm_nt(g, w[:, ka:], True, None, None, None, xb.size(1))
         want_bias = ctx.has_bias and need[3]
         if need[2] or want_bias:
-            gw = torch.empty_like(w, memory_format=torch.contiguous_format)
-            _, gb = _gemm_tn(g, xa, want_bias, gw[:, :ka])
-            _gemm_tn(g, xb, False, gw[:, ka:])
-        return gxa, gxb, gw if need[2] else None, gb
+            wbuf = _grad_buffer(w) if need[2] else None
+            bbuf = _grad_buffer(bias) if want_bias else None
+            if wbuf is not None and (not want_bias or bbuf is not None):     # add both halves into w.grad
+                _gemm_tn(g, xa, want_bias, wbuf[:, :ka], bbuf, accumulate=True)
+                _gemm_tn(g, xb, False, wbuf[:, ka:], None, accumulate=True)
+            else:
+                gw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                _, gb = _gemm_tn(g, xa, want_bias, gw[:, :ka])
+                _gemm_tn(g, xb, False, gw[:, ka:])
+                if not need[2]:
+                    gw = None
+        return gxa, gxb, gw, gb
 
 
 def concat_linear(xa, xb, w, bias=None):
@@ -279,12 +335,12 @@ class _SageConv(torch.autograd.Function):
                       None, _lib.ptr(bias2), n, 2 * n_out, tr.data_ptr(), ld_of(tr), _lib.stream())
             y = new_padded(n, n_out, x.device)
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
-            ctx.save_for_backward(x, wl, wr)
+            ctx.save_for_backward(x, wl, wr, bl)
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
             y = _gemm_nt(agg, wl, False, x, wr, bl, n_out)
-            ctx.save_for_backward(x, wl, wr, agg)
+            ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
         return y
 
@@ -298,19 +354,19 @@ class _SageConv(torch.autograd.Function):
         inv = graph.inv_deg if mean else None
         gx = None
         if ctx.first:
-            x, wl, wr = ctx.saved_tensors
+            x, wl, wr, bl = ctx.saved_tensors
             n_out, n_in = wl.shape
             gt = new_padded(n, n_out, g.device, zero_pad=False)      # gradient of the aggregated half
             _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
-            gwl, _ = _gemm_tn(gt, x, False)
-            gwr, gb = _gemm_tn(g, x, want_bias)
+            gwl, _ = _weight_grad(gt, x, wl)
+            gwr, gb = _weight_grad(g, x, wr, bl, want_bias)
             if need[0]:
                 gx = _gemm_nt(gt, wl, True, g, wr, None, n_in)
         else:
-            x, wl, wr, agg = ctx.saved_tensors
+            x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
-            gwl, gb = _gemm_tn(g, agg, want_bias)
-            gwr, _ = _gemm_tn(g, x, False)
+            gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
+            gwr, _ = _weight_grad(g, x, wr)
             if need[0]:
                 t = _gemm_nt(g, wl, True, None, None, None, n_in)
                 gr = _gemm_nt(g, wr, True, None, None, None, n_in)

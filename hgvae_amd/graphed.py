@@ -17,6 +17,7 @@ from typing import Callable, Optional
 import torch
 
 from .distributed import FlatGradBucket
+from .functional import direct_weight_grads
 from .graph import graph_of
 from .noise import PhiloxNoise, use_noise
 from .vae import train_step_loss
@@ -61,7 +62,8 @@ class GraphedTrainStep:
         self.bucket.zero()
         with use_noise(self.noise):
             loss = self.loss_fn(self.model, self.x, self.edge_index, self.batch, self.lambda_kl)
-        loss.backward()
+        with direct_weight_grads():
+            loss.backward()
         if reduce:
             self.bucket.all_reduce_mean()
         if step_optimizer:

@@ -173,7 +173,8 @@ int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* o
  * The weights are first packed into ws (hgv_gemm_nt_ws bytes); callers that reuse a weight can pack once
  * with hgv_pack_weight (hgv_pack_bytes bytes per weight) and call hgv_gemm_nt_packed.
  * hgv_gemm_tn:  GW[N,K] (row-major, leading dimension ldgw >= K, so that it can be a column block of a wider
- * weight gradient) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable).  G, A: row-major, any 4-byte
+ * weight gradient) = G[M,N]^T A[M,K];  gbias[N] = column sums of G (nullable); accumulate != 0 adds to GW / gbias
+ * instead of overwriting them (accumulation into an existing .grad buffer).  G, A: row-major, any 4-byte
  * aligned pointers, leading dimensions >= their widths.  The reduction over M is split over workgroups and
  * combined in a fixed order (reproducible). */
 int hgv_pack_rows(int N);
@@ -192,7 +193,7 @@ int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W1, int64_t 
                 float* C, int64_t ldc, void* ws, size_t ws_bytes, hgv_stream_t stream);
 size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
-                int64_t ldgw, float* gbias, void* ws, size_t ws_bytes, hgv_stream_t stream);
+                int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 /* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
  *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------

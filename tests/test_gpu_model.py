@@ -350,3 +350,31 @@ def test_training_with_torch_adam_tracks_flat_adam(fused):
     assert a[-1] < a[0]                       # it trains
     for x, y in zip(a, b):
         assert abs(x - y) <= 2e-4 * abs(x), (a, b)
+
+
+def test_direct_weight_grads_match_autograd_accumulation():
+    """Gradients added by the reduction kernel straight into the bucket views equal the ones autograd
+    accumulates from returned tensors (same kernels; only the final add differs in rounding order)."""
+    import hgvae_amd
+    from hgvae_amd import functional as Fn
+    from hgvae_amd import synthetic
+    from hgvae_amd.distributed import FlatGradBucket
+    from hgvae_amd.vae import SkipconVAE, train_step_loss
+    dev = torch.device("cuda:0")
+    batch = synthetic.path_graph_batch([138] * 6 + [77], 60, seed=11, device=dev)
+    flats = []
+    for direct in (False, True):
+        torch.manual_seed(0)
+        hgvae_amd.manual_seed(5)
+        model = SkipconVAE(60, 138, 28).to(dev).train()
+        bucket = FlatGradBucket(model.parameters())
+        for _ in range(2):                      # second step: buffers already hold values that must be zeroed, not kept
+            bucket.zero()
+            loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+            with Fn.direct_weight_grads(direct):
+                loss.backward()
+            bucket.gather()
+        flats.append(bucket.flat.clone())
+    a, b = flats
+    assert float(a.abs().max()) > 0
+    assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
