@@ -58,6 +58,27 @@ __global__ __launch_bounds__(256) void k_pack_weight_rows(const float* __restric
     }
 }
 
+// up to 4 packed images in one launch (the weights of one operator call, both orientations)
+struct PackJobs {
+    const float* W[4]; int64_t sn[4], sk[4];
+    int N[4], K[4], R[4], Gp[4];
+    float* out[4];
+    int64_t start[5];          // element ranges of the jobs in the flat index space
+    int njobs;
+};
+__global__ __launch_bounds__(256) void k_pack_weights(const PackJobs j) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < j.start[j.njobs]; e += (int64_t)gridDim.x * blockDim.x) {
+        int q = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t) q += (t < j.njobs && e >= j.start[t]) ? 1 : 0;
+        const int64_t l = e - j.start[q];
+        const int R = j.R[q];
+        const int gidx = (int)(l / (R * 4)), rem = (int)(l - (int64_t)gidx * R * 4);
+        const int n = rem >> 2, k = 4 * gidx + (rem & 3);
+        j.out[q][l] = (n < j.N[q] && k < j.K[q]) ? j.W[q][(int64_t)n * j.sn[q] + (int64_t)k * j.sk[q]] : 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // NT kernel, weights resident in LDS
 // ------------------------------------------------------------------------------------------
@@ -743,6 +764,29 @@ extern "C" int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, in
     const int64_t total = (int64_t)rows * Gp * 4;
     hipLaunchKernelGGL(k_pack_weight, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, W, sn, sk, N, K, out, rows, Gp);
     HGV_CHECK_LAUNCH("pack_weight");
+    return HGV_OK;
+}
+
+// Up to 4 packed images in one launch: job q packs W[q] (element (n,k) at W[q][n*sn[q] + k*sk[q]], N[q] x K[q])
+// into out[q] (hgv_pack_bytes(N[q], K[q]) bytes).  The arrays are host arrays of njobs entries.
+extern "C" int hgv_pack_weights(int njobs, const float* const* W, const int64_t* sn, const int64_t* sk, const int* N,
+                                const int* K, float* const* out, hipStream_t stream) {
+    HGV_REQUIRE(njobs >= 1 && njobs <= 4 && W && sn && sk && N && K && out, HGV_EINVAL, "pack_weights: 1..4 jobs");
+    PackJobs j{};
+    j.njobs = njobs;
+    int64_t total = 0;
+    for (int q = 0; q < njobs; ++q) {
+        HGV_REQUIRE(W[q] && out[q] && N[q] > 0 && K[q] > 0, HGV_EINVAL, "pack_weights: bad job %d", q);
+        HGV_REQUIRE(N[q] <= 288, HGV_EUNSUPPORTED, "pack_weights: N=%d > 288", N[q]);
+        HGV_REQUIRE(hgv_aligned(out[q], 16), HGV_EINVAL, "pack_weights: output %d must be 16-byte aligned", q);
+        j.W[q] = W[q]; j.sn[q] = sn[q]; j.sk[q] = sk[q]; j.N[q] = N[q]; j.K[q] = K[q];
+        j.R[q] = hgv_pack_rows(N[q]); j.Gp[q] = kp_of(K[q]) / 4; j.out[q] = out[q];
+        j.start[q] = total;
+        total += (int64_t)j.R[q] * j.Gp[q] * 4;
+    }
+    for (int q = njobs; q <= 4; ++q) j.start[q] = total;
+    hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, j);
+    HGV_CHECK_LAUNCH("pack_weights");
     return HGV_OK;
 }
 

@@ -124,28 +124,47 @@ class _WeightedAggregate(torch.autograd.Function):
 MAX_GEMM_N = 288
 
 
-def _packed(w: torch.Tensor, transposed: bool) -> torch.Tensor:
-    """Packed image of a weight (or of its transpose) for the NT kernel, built at every use.
+def _pack(*specs):
+    """Packed images for the NT kernel, built by ONE launch at every use: ``specs`` are up to four
+    ``(weight, transposed)`` pairs (None entries are skipped and returned as None); ``transposed``
+    packs w^T, the operand of the grad-input product.
 
-    The image is not cached across calls: ``Tensor._version`` is the only cheap change signal and it
+    Images are not cached across calls: ``Tensor._version`` is the only cheap change signal and it
     misses real updates (``torch.optim.Adam(fused=True)`` and writes through ``.data`` leave it
-    untouched), and a stale image silently trains against old weights.  Packing is one small launch
-    (<= 161 KB written); the buffer comes from the caching allocator, so it is recycled in stream order.
+    untouched), and a stale image silently trains against old weights.  An operator packs what its
+    forward AND backward need when it runs forward (the weights backward must use are the forward
+    ones anyway) and keeps the transposed images until backward.
     """
-    n, k = (w.size(1), w.size(0)) if transposed else (w.size(0), w.size(1))
-    sn, sk = (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
-    buf = torch.empty(_lib.load().hgv_pack_bytes(n, k) // 4, dtype=torch.float32, device=w.device)
-    _lib.call("hgv_pack_weight", w.data_ptr(), sn, sk, n, k, buf.data_ptr(), _lib.stream())
-    return buf
+    import ctypes as C
+    live = [(i, w, t) for i, sp in enumerate(specs) if sp is not None for (w, t) in [sp]]
+    out = [None] * len(specs)
+    if not live:
+        return out
+    lib = _lib.load()
+    dims = [((w.size(1), w.size(0)) if t else (w.size(0), w.size(1))) for (_, w, t) in live]
+    sizes = [lib.hgv_pack_bytes(n, k) // 4 for (n, k) in dims]
+    buf = torch.empty(sum(sizes), dtype=torch.float32, device=live[0][1].device)
+    nj = len(live)
+    Wp, Op = (C.c_void_p * nj)(), (C.c_void_p * nj)()
+    sn, sk = (C.c_int64 * nj)(), (C.c_int64 * nj)()
+    N, K = (C.c_int * nj)(), (C.c_int * nj)()
+    off = 0
+    for q, ((i, w, t), (n, k), sz) in enumerate(zip(live, dims, sizes)):
+        piece = buf[off:off + sz]
+        off += sz
+        out[i] = piece
+        Wp[q], Op[q] = w.data_ptr(), piece.data_ptr()
+        sn[q], sk[q] = (w.stride(1), w.stride(0)) if t else (w.stride(0), w.stride(1))
+        N[q], K[q] = n, k
+    _lib.call("hgv_pack_weights", nj, Wp, sn, sk, N, K, Op, _lib.stream())
+    return out
 
 
-def _gemm_nt(xa, wa, wa_t: bool, xb, wb, bias, n_out: int) -> torch.Tensor:
-    """out[M, n_out] = xa @ op(wa)^T (+ xb @ op(wb)^T) (+ bias); op(w) = w ([n_out, K]) or, with
-    ``wa_t``, w^T (w is [K, n_out]).  xa / xb must already be in the padded layout."""
+def _gemm_nt(xa, pa, xb, pb, bias, n_out: int) -> torch.Tensor:
+    """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with packed images ``pa`` / ``pb`` (see
+    :func:`_pack`) of the [n_out, K] operands.  xa / xb must already be in the padded layout."""
     m = xa.size(0)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
-    pa = _packed(wa, wa_t)
-    pb = _packed(wb, wa_t) if xb is not None else None
     _lib.call("hgv_gemm_nt_packed", xa.data_ptr(), ld_of(xa), xa.size(1), pa.data_ptr(),
               _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, _lib.ptr(pb),
               _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
@@ -222,7 +241,11 @@ class _DualLinear(torch.autograd.Function):
                                 f"(got {tuple(wa.shape)}{'' if wb is None else ' and ' + str(tuple(wb.shape))})")
         xa = as_padded(xa)
         xb = as_padded(xb) if xb is not None else None
-        y = _gemm_nt(xa, wa, False, xb, wb, bias, wa.size(0))
+        need = ctx.needs_input_grad
+        pa, pb, ctx.pat, ctx.pbt = _pack((wa, False), (wb, False) if xb is not None else None,
+                                         (wa, True) if need[0] else None,
+                                         (wb, True) if xb is not None and need[2] else None)
+        y = _gemm_nt(xa, pa, xb, pb, bias, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.save_for_backward(xa, wa, xb, wb, bias)
         return y
@@ -235,14 +258,14 @@ class _DualLinear(torch.autograd.Function):
         gxa = gwa = gxb = gwb = gb = None
         want_bias = ctx.has_bias and need[4]
         if need[0]:
-            gxa = _gemm_nt(g, wa, True, None, None, None, wa.size(1))
+            gxa = _gemm_nt(g, ctx.pat, None, None, None, wa.size(1))
         if need[1]:
             gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
         elif want_bias:
             _, gb = _gemm_tn(g, xa, True)
         if ctx.has_b:
             if need[2]:
-                gxb = _gemm_nt(g, wb, True, None, None, None, wb.size(1))
+                gxb = _gemm_nt(g, ctx.pbt, None, None, None, wb.size(1))
             if need[3]:
                 gwb, _ = _weight_grad(g, xb, wb)
         return gxa, gwa, gxb, gwb, gb
@@ -263,7 +286,11 @@ class _ConcatLinear(torch.autograd.Function):
         if max(w.size(0), ka, kb) > MAX_GEMM_N:
             raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported (got {tuple(w.shape)})")
         xa, xb = as_padded(xa), as_padded(xb)
-        y = _gemm_nt(xa, w[:, :ka], False, xb, w[:, ka:], bias, w.size(0))
+        need = ctx.needs_input_grad
+        wa, wb = w[:, :ka], w[:, ka:]
+        pa, pb, ctx.pat, ctx.pbt = _pack((wa, False), (wb, False), (wa, True) if need[0] else None,
+                                         (wb, True) if need[1] else None)
+        y = _gemm_nt(xa, pa, xb, pb, bias, w.size(0))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xa, xb, w, bias)
         return y
@@ -276,9 +303,9 @@ class _ConcatLinear(torch.autograd.Function):
         need = ctx.needs_input_grad
         gxa = gxb = gw = gb = None
         if need[0]:
-            gxa = _gemm_nt(g, w[:, :ka], True, None, None, None, ka)
+            gxa = _gemm_nt(g, ctx.pat, None, None, None, ka)
         if need[1]:
-            gxb = _gemm_nt(g, w[:, ka:], True, None, None, None, xb.size(1))
+            gxb = _gemm_nt(g, ctx.pbt, None, None, None, xb.size(1))
         want_bias = ctx.has_bias and need[3]
         if need[2] or want_bias:
             wbuf = _grad_buffer(w) if need[2] else None
@@ -335,11 +362,15 @@ class _SageConv(torch.autograd.Function):
                       None, _lib.ptr(bias2), n, 2 * n_out, tr.data_ptr(), ld_of(tr), _lib.stream())
             y = new_padded(n, n_out, x.device)
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
+            _, _, ctx.plt, ctx.prt = _pack(None, None, (wl, True) if ctx.needs_input_grad[0] else None,
+                                           (wr, True) if ctx.needs_input_grad[0] else None)
             ctx.save_for_backward(x, wl, wr, bl)
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
-            y = _gemm_nt(agg, wl, False, x, wr, bl, n_out)
+            pl, pr, ctx.plt, ctx.prt = _pack((wl, False), (wr, False), (wl, True) if ctx.needs_input_grad[0] else None,
+                                             (wr, True) if ctx.needs_input_grad[0] else None)
+            y = _gemm_nt(agg, pl, x, pr, bl, n_out)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
         return y
@@ -361,15 +392,15 @@ class _SageConv(torch.autograd.Function):
             gwl, _ = _weight_grad(gt, x, wl)
             gwr, gb = _weight_grad(g, x, wr, bl, want_bias)
             if need[0]:
-                gx = _gemm_nt(gt, wl, True, g, wr, None, n_in)
+                gx = _gemm_nt(gt, ctx.plt, g, ctx.prt, None, n_in)
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
             gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
             gwr, _ = _weight_grad(g, x, wr)
             if need[0]:
-                t = _gemm_nt(g, wl, True, None, None, None, n_in)
-                gr = _gemm_nt(g, wr, True, None, None, None, n_in)
+                t = _gemm_nt(g, ctx.plt, None, None, None, n_in)
+                gr = _gemm_nt(g, ctx.prt, None, None, None, n_in)
                 gx = new_padded(n, n_in, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, t, n_in, 0, None, None, inv, gr, gx)
         return gx, gwl, gb, gwr, None, None

@@ -180,6 +180,9 @@ int hgv_gather_i64(const int64_t* src, const int64_t* idx, int64_t n, int64_t* o
 int hgv_pack_rows(int N);
 size_t hgv_pack_bytes(int N, int K);
 int hgv_pack_weight(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, hgv_stream_t stream);
+/* Up to 4 weights (or orientations of weights) packed by one launch; host arrays of njobs entries. */
+int hgv_pack_weights(int njobs, const float* const* W, const int64_t* sn, const int64_t* sk, const int* N, const int* K,
+                     float* const* out, hgv_stream_t stream);
 /* One weight into rows [row_offset, row_offset+N) of the packed image of an [n_total, K] weight that stacks
  * several weights along N (rows of the image not covered by a weight must be zero). */
 int hgv_pack_weight_rows(const float* W, int64_t sn, int64_t sk, int N, int K, float* out, int row_offset,

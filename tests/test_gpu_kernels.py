@@ -475,13 +475,14 @@ def test_projection_kernels_at_benchmark_rows(shape):
     w = torch.randn(n, k1 + (k2 or 0), generator=gen, device=dev())
     bias = torch.randn(n, generator=gen, device=dev())
     g = rnd(m, n)
-    y = Fn._gemm_nt(xa, w[:, :k1], False, xb, w[:, k1:] if k2 else None, bias, n)
+    pa, pb, pat = Fn._pack((w[:, :k1], False), (w[:, k1:], False) if k2 else None, (w[:, :k1], True))
+    y = Fn._gemm_nt(xa, pa, xb, pb, bias, n)
     ref = xa.double() @ w[:, :k1].double().t() + bias.double()
     if k2:
         ref = ref + xb.double() @ w[:, k1:].double().t()
     scale = float(ref.abs().max())
     assert float((y.double() - ref).abs().max()) <= 2e-6 * scale * (k1 + (k2 or 0)) ** 0.5
-    gx = Fn._gemm_nt(g, w[:, :k1], True, None, None, None, k1)           # grad-input product
+    gx = Fn._gemm_nt(g, pat, None, None, None, k1)                        # grad-input product
     refx = g.double() @ w[:, :k1].double()
     assert float((gx.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max()) * n ** 0.5
     gw, gb = Fn._gemm_tn(g, xa, True)

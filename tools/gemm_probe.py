@@ -23,6 +23,11 @@ def timeit(fn, iters=20):
     return ts[len(ts) // 2]
 
 
+def nt_call(xa, wa, xb, wb, bias, n):
+    pa, pb = Fn._pack((wa, False), (wb, False) if xb is not None else None)
+    return Fn._gemm_nt(xa, pa, xb, pb, bias, n)
+
+
 def main():
     dev = torch.device("cuda:0")
     m = int(os.environ.get("M", 160984))
@@ -39,7 +44,7 @@ def main():
         wa, wb = w[:, :k1], (w[:, k1:] if k2 else None)
         bias = torch.randn(n, device=dev)
         g = new_padded(m, n, dev); g.normal_()
-        t_nt = 1.0 if os.environ.get("TN_ONLY") else timeit(lambda: Fn._gemm_nt(xa, wa, False, xb, wb, bias, n))
+        t_nt = 1.0 if os.environ.get("TN_ONLY") else timeit(lambda: nt_call(xa, wa, xb, wb, bias, n))
         fl = 2.0 * m * (k1 + (k2 or 0)) * n
         t_tn = timeit(lambda: Fn._gemm_tn(g, xa, True))
         fl_tn = 2.0 * m * n * k1
