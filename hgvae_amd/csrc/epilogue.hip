@@ -205,8 +205,10 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var,
                                                            float* __restrict__ save_mean,
-                                                           float* __restrict__ save_rstd) {
+                                                           float* __restrict__ save_rstd,
+                                                           int64_t* __restrict__ num_batches_tracked) {
     __shared__ double sh[FIN_SL][17];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < H;
@@ -369,7 +371,8 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
 
 __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
                                                          int Hp, float* __restrict__ sums,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         int accumulate) {
     __shared__ double sh[FIN_SL][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -397,8 +400,8 @@ __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restric
     sums[c] = (float)s1;
     sums[Hp + c] = (float)s2;
     if (c < H) {
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
     }
 }
 
@@ -481,14 +484,14 @@ extern "C" size_t hgv_bn_act_ws(int64_t N, int H) {
     return hgv_align256(2048 * 2 * Hp * sizeof(float)) + hgv_align256(2 * Hp * sizeof(float));
 }
 
-// Training-mode forward.  mask: explicit keep mask [N,H] (uint8, contiguous) or null; with
+// Training-mode forward.  num_batches_tracked (nullable device int64) is incremented.  mask: explicit keep mask [N,H] (uint8, contiguous) or null; with
 // p > 0 and no mask the keep decisions come from Philox4x32 keyed by (seed, offset, row, chunk pair),
 // 16 random bits per element, and the backward pass regenerates them from the same (seed, offset).
 extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
                               uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma,
                               const float* beta, float eps,
-                              float* running_mean, float* running_var, float momentum, float* save_mean,
-                              float* save_rstd, float* out, int64_t ldo, void* ws, size_t ws_bytes,
+                              float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                              float* save_mean, float* save_rstd, float* out, int64_t ldo, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
     EpArgs a; int nb;
     int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
@@ -501,7 +504,7 @@ extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int
     if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
     else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
     hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, N,
-                       H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd);
+                       H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked);
     NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
     if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
     else hipLaunchKernelGGL(k_ep_apply<false>, dim3(nb), dim3(256), 0, stream, a, n);
@@ -525,12 +528,14 @@ extern "C" int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, in
     return HGV_OK;
 }
 
-// Backward of the training-mode forward: dy (w.r.t. the pre-activation), dgamma, dbeta.
+// Backward of the training-mode forward: dy (w.r.t. the pre-activation), dgamma, dbeta
+// (accumulate != 0: added to dgamma / dbeta, i.e. straight into existing .grad buffers).
 extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu,
                               float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
                               const uint64_t* offset_dev, const float* gamma,
                               const float* save_mean, const float* save_rstd, float* dy, int64_t lddy,
-                              float* dgamma, float* dbeta, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
     EpArgs a; int nb;
     int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
@@ -543,7 +548,7 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(dy, lddy, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_stats<true>, dim3(nb), dim3(256), 0, stream, a, b, partial);
     else hipLaunchKernelGGL(k_ep_bwd_stats<false>, dim3(nb), dim3(256), 0, stream, a, b, partial);
-    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_apply<true>, dim3(nb), dim3(256), 0, stream, a, b);
     else hipLaunchKernelGGL(k_ep_bwd_apply<false>, dim3(nb), dim3(256), 0, stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd");

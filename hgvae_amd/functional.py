@@ -421,7 +421,8 @@ def dual_linear(xa, wa, xb=None, wb=None, bias=None):
 # --------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum,
+                tracked=None):
         _lib.require_cuda(y)
         y = rowmajor(y)
         n, h = y.shape
@@ -434,30 +435,35 @@ class _BnAct(torch.autograd.Function):
         save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
         _lib.call("hgv_bn_act_fwd", y.data_ptr(), ld_of(y), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
                   _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
-                  float(momentum), save_mean.data_ptr(), save_rstd.data_ptr(), out.data_ptr(), ld_of(out),
-                  ws.data_ptr(), ws.numel(), _lib.stream())
+                  float(momentum), _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), out.data_ptr(),
+                  ld_of(out), ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (relu, p, seed, offset, ctr)
-        ctx.save_for_backward(y, gamma, save_mean, save_rstd, mask)
+        ctx.save_for_backward(y, gamma, save_mean, save_rstd, mask, beta)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        y, gamma, save_mean, save_rstd, mask = ctx.saved_tensors
+        y, gamma, save_mean, save_rstd, mask, beta = ctx.saved_tensors
         relu, p, seed, offset, ctr = ctx.cfg
         g = rowmajor(g)
         n, h = y.shape
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
         dy = new_padded(n, h, y.device, zero_pad=False)
-        dgamma = torch.empty(h, dtype=torch.float32, device=y.device)
-        dbeta = torch.empty(h, dtype=torch.float32, device=y.device)
+        need = ctx.needs_input_grad
+        # affine gradients: straight into the parameters' .grad buffers when that mode is on
+        gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
+        direct = gbuf is not None and bbuf is not None
+        dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=y.device)
+        dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=y.device)
         _lib.call("hgv_bn_act_bwd", g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), n, h, int(relu), float(p),
                   _lib.ptr(mask), seed, offset, ctr, _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
-                  dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(),
-                  _lib.stream())
-        need = ctx.needs_input_grad
+                  dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(),
+                  ws.numel(), _lib.stream())
+        if direct:
+            dgamma = dbeta = None
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool) -> torch.Tensor:
@@ -474,11 +480,9 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
     if p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
-    out = _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, ctr,
-                       bn.eps, momentum)
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return out
+    # num_batches_tracked is incremented by the statistics kernel
+    return _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, ctr,
+                        bn.eps, momentum, bn.num_batches_tracked)
 
 
 # --------------------------------------------------------------------------------------

@@ -85,15 +85,16 @@ int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, c
 size_t hgv_bn_act_ws(int64_t N, int H);
 int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
-                   float* running_mean, float* running_var, float momentum, float* save_mean, float* save_rstd,
-                   float* out, int64_t ldo, void* ws, size_t ws_bytes, hgv_stream_t stream);
+                   float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                   float* save_mean, float* save_rstd, float* out, int64_t ldo, void* ws, size_t ws_bytes,
+                   hgv_stream_t stream);
 int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, int relu, const float* gamma, const float* beta,
                     float eps, const float* running_mean, const float* running_var, float* out, int64_t ldo,
                     hgv_stream_t stream);
 int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
                    const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* save_mean,
-                   const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* ws,
-                   size_t ws_bytes, hgv_stream_t stream);
+                   const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, int accumulate,
+                   void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 /* ---- reparameterisation / KL / MSE: gvae/gvae_skipcon.py:138-142, :153-156, :174 ----------
  * ml = [mean | log_std], [N, 2Z] with leading dimension ldm.

@@ -537,3 +537,25 @@ def test_flat_adam_invalidates_packed_weights():
     y1 = Fn.dual_linear(x, w).detach()
     close(y1, x.double().cpu() @ w.detach().double().cpu().t(), 2e-6)
     assert float((y1 - y0.detach()).abs().max()) > 1e-2
+
+
+def test_bn_act_counts_batches_and_accumulates_affine_grads_in_place():
+    """num_batches_tracked is advanced by the statistics kernel (BatchNorm1d semantics), and with
+    direct_weight_grads the affine gradients are added to existing .grad buffers."""
+    from hgvae_amd import functional as Fn
+    gen = torch.Generator().manual_seed(2)
+    bn = torch.nn.BatchNorm1d(10).to(dev())
+    y = torch.randn(50, 10, generator=gen).to(dev()).requires_grad_(True)
+    gout = torch.randn(50, 10, generator=gen).to(dev())
+    out = Fn.bn_act(y, bn, True, 0.0, True)
+    out.backward(gout)
+    assert int(bn.num_batches_tracked) == 1
+    want_w, want_b = bn.weight.grad.clone(), bn.bias.grad.clone()
+    bn.weight.grad.fill_(1.0)
+    bn.bias.grad.fill_(2.0)
+    out = Fn.bn_act(y, bn, True, 0.0, True)
+    with Fn.direct_weight_grads():
+        out.backward(gout)
+    assert int(bn.num_batches_tracked) == 2
+    close(bn.weight.grad, (want_w + 1.0).cpu(), 1e-6)
+    close(bn.bias.grad, (want_b + 2.0).cpu(), 1e-6)

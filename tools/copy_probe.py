@@ -15,14 +15,17 @@ def main():
     dev = torch.device("cuda:0")
     batch = synthetic.protein_like_batch(2, seed=1, device=dev, nodes=(500, 600))
     model = vae.SkipconVAE(105, 138, 28).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    bucket = FlatGradBucket(model.parameters())
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd import functional as Fn
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    bucket = opt.bucket
     x = vae.padded_input(batch.x)
 
     def step():
         bucket.zero()
         loss = vae.train_step_loss(model, x, batch.edge_index, batch.batch, 1.0)
-        loss.backward()
+        with Fn.direct_weight_grads():
+            loss.backward()
         bucket.all_reduce_mean()
         opt.step()
 
@@ -35,7 +38,7 @@ def main():
     import collections
     cnt = collections.Counter()
     for ev in prof.events():
-        if ev.name in ("aten::copy_", "aten::cat", "aten::clone", "aten::contiguous", "aten::zeros_like", "aten::fill_", "aten::zero_", "aten::add_", "aten::add", "aten::mul", "aten::sum"):
+        if ev.name.startswith("aten::") and ev.name not in ("aten::empty", "aten::as_strided", "aten::view", "aten::slice", "aten::empty_strided", "aten::select", "aten::detach", "aten::alias", "aten::expand", "aten::t", "aten::transpose", "aten::unsqueeze", "aten::_unsafe_view", "aten::reshape", "aten::narrow", "aten::empty_like", "aten::result_type", "aten::to", "aten::lift_fresh", "aten::item", "aten::_local_scalar_dense", "aten::chunk", "aten::split"):
             stack = [s for s in (ev.stack or []) if "hgvae_amd" in s or "tools/" in s]
             cnt[(ev.name, str(ev.input_shapes)[:60], stack[0][-60:] if stack else "")] += 1
     for k, v in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
