@@ -5,7 +5,7 @@
 
 One "step" is the reference's train_vae body for one mini-batch (gvae/gvae_skipcon.py:163-185):
 forward, second encode, mse + kl, backward, gradient all-reduce (N > 1), Adam step.
-Default workload: BASELINE config "synthetic protein-like graphs (~5k nodes, ~60k edges each),
+Default workload: the headline configuration "synthetic protein-like graphs (~5k nodes, ~60k edges each),
 batch 256 over 8 GPUs" - each rank holds its 32-graph shard (weak scaling), model
 VAE(105, 138, 28) of gvae_skipcon.  Inputs are resident in HBM before the timed region.
 
