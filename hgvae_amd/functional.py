@@ -7,6 +7,7 @@ re-implementation.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Optional
 
 import torch
@@ -160,14 +161,60 @@ def _pack(*specs):
     return out
 
 
-def _gemm_nt(xa, pa, xb, pb, bias, n_out: int) -> torch.Tensor:
-    """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with packed images ``pa`` / ``pb`` (see
-    :func:`_pack`) of the [n_out, K] operands.  xa / xb must already be in the padded layout."""
+# Projection arithmetic: "bf16x6" (default) runs fp32-accurate products on the bf16 matrix cores
+# (every operand split into three bf16 pieces, six piece products, fp32 accumulation: same measured
+# error as the fp32 MFMA chain, ~1.5x faster); "fp32" keeps v_mfma_f32_16x16x4_f32.  Shapes whose
+# split weight image does not fit in LDS use the fp32 kernels either way.
+_projection = os.environ.get("HGVAE_PROJECTION", "bf16x6")
+
+
+def set_projection(kind: str) -> None:
+    global _projection
+    if kind not in ("bf16x6", "fp32"):
+        raise ValueError("projection arithmetic is 'bf16x6' or 'fp32'")
+    _projection = kind
+
+
+class _Image:
+    """Packed weight operand of one NT product: a split-bf16 image of [Wa | Wb] or fp32 images of Wa, Wb."""
+    __slots__ = ("kind", "a", "b")
+
+    def __init__(self, kind, a, b=None):
+        self.kind, self.a, self.b = kind, a, b
+
+
+def _image(wa: torch.Tensor, wb: Optional[torch.Tensor], transposed: bool) -> _Image:
+    """Weight image for ``x_a @ op(wa)^T (+ x_b @ op(wb)^T)`` with op(w) = w or, with ``transposed``,
+    w^T (the grad-input product).  Built at every use (see :func:`_pack`)."""
+    lib = _lib.load()
+    n, k1 = (wa.size(1), wa.size(0)) if transposed else (wa.size(0), wa.size(1))
+    k2 = 0 if wb is None else (wb.size(0) if transposed else wb.size(1))
+    if _projection == "bf16x6" and lib.hgv_gemm_nt16_supported(n, k1, k2):
+        buf = torch.empty(lib.hgv_pack16_bytes(n, k1, k2) // 4, dtype=torch.float32, device=wa.device)
+
+        def st(w):
+            return (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
+        sa, sb = st(wa), (st(wb) if wb is not None else (0, 0))
+        _lib.call("hgv_pack16_weights", wa.data_ptr(), sa[0], sa[1], k1, _lib.ptr(wb), sb[0], sb[1], k2, n,
+                  buf.data_ptr(), _lib.stream())
+        return _Image("bf16x6", buf)
+    pa, pb = _pack((wa, transposed), (wb, transposed) if wb is not None else None)
+    return _Image("fp32", pa, pb)
+
+
+def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
+    """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
+    xa / xb must already be in the padded layout."""
     m = xa.size(0)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
-    _lib.call("hgv_gemm_nt_packed", xa.data_ptr(), ld_of(xa), xa.size(1), pa.data_ptr(),
-              _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, _lib.ptr(pb),
-              _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
+    if img.kind == "bf16x6":
+        _lib.call("hgv_gemm_nt16", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
+                  ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
+                  _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
+    else:
+        _lib.call("hgv_gemm_nt_packed", xa.data_ptr(), ld_of(xa), xa.size(1), img.a.data_ptr(),
+                  _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0,
+                  _lib.ptr(img.b), _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
     return out
 
 
@@ -242,10 +289,9 @@ class _DualLinear(torch.autograd.Function):
         xa = as_padded(xa)
         xb = as_padded(xb) if xb is not None else None
         need = ctx.needs_input_grad
-        pa, pb, ctx.pat, ctx.pbt = _pack((wa, False), (wb, False) if xb is not None else None,
-                                         (wa, True) if need[0] else None,
-                                         (wb, True) if xb is not None and need[2] else None)
-        y = _gemm_nt(xa, pa, xb, pb, bias, wa.size(0))
+        ctx.pat = _image(wa, None, True) if need[0] else None
+        ctx.pbt = _image(wb, None, True) if xb is not None and need[2] else None
+        y = _gemm_nt(xa, _image(wa, wb if xb is not None else None, False), xb, bias, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.save_for_backward(xa, wa, xb, wb, bias)
         return y
@@ -258,14 +304,14 @@ class _DualLinear(torch.autograd.Function):
         gxa = gwa = gxb = gwb = gb = None
         want_bias = ctx.has_bias and need[4]
         if need[0]:
-            gxa = _gemm_nt(g, ctx.pat, None, None, None, wa.size(1))
+            gxa = _gemm_nt(g, ctx.pat, None, None, wa.size(1))
         if need[1]:
             gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
         elif want_bias:
             _, gb = _gemm_tn(g, xa, True)
         if ctx.has_b:
             if need[2]:
-                gxb = _gemm_nt(g, ctx.pbt, None, None, None, wb.size(1))
+                gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
             if need[3]:
                 gwb, _ = _weight_grad(g, xb, wb)
         return gxa, gwa, gxb, gwb, gb
@@ -288,9 +334,9 @@ class _ConcatLinear(torch.autograd.Function):
         xa, xb = as_padded(xa), as_padded(xb)
         need = ctx.needs_input_grad
         wa, wb = w[:, :ka], w[:, ka:]
-        pa, pb, ctx.pat, ctx.pbt = _pack((wa, False), (wb, False), (wa, True) if need[0] else None,
-                                         (wb, True) if need[1] else None)
-        y = _gemm_nt(xa, pa, xb, pb, bias, w.size(0))
+        ctx.pat = _image(wa, None, True) if need[0] else None
+        ctx.pbt = _image(wb, None, True) if need[1] else None
+        y = _gemm_nt(xa, _image(wa, wb, False), xb, bias, w.size(0))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xa, xb, w, bias)
         return y
@@ -303,9 +349,9 @@ class _ConcatLinear(torch.autograd.Function):
         need = ctx.needs_input_grad
         gxa = gxb = gw = gb = None
         if need[0]:
-            gxa = _gemm_nt(g, ctx.pat, None, None, None, ka)
+            gxa = _gemm_nt(g, ctx.pat, None, None, ka)
         if need[1]:
-            gxb = _gemm_nt(g, ctx.pbt, None, None, None, xb.size(1))
+            gxb = _gemm_nt(g, ctx.pbt, None, None, xb.size(1))
         want_bias = ctx.has_bias and need[3]
         if need[2] or want_bias:
             wbuf = _grad_buffer(w) if need[2] else None
@@ -362,15 +408,14 @@ class _SageConv(torch.autograd.Function):
                       None, _lib.ptr(bias2), n, 2 * n_out, tr.data_ptr(), ld_of(tr), _lib.stream())
             y = new_padded(n, n_out, x.device)
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
-            _, _, ctx.plt, ctx.prt = _pack(None, None, (wl, True) if ctx.needs_input_grad[0] else None,
-                                           (wr, True) if ctx.needs_input_grad[0] else None)
+            ctx.pt = _image(wl, wr, True) if ctx.needs_input_grad[0] else None     # gx = gt wl + g wr
             ctx.save_for_backward(x, wl, wr, bl)
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
-            pl, pr, ctx.plt, ctx.prt = _pack((wl, False), (wr, False), (wl, True) if ctx.needs_input_grad[0] else None,
-                                             (wr, True) if ctx.needs_input_grad[0] else None)
-            y = _gemm_nt(agg, pl, x, pr, bl, n_out)
+            ctx.plt = _image(wl, None, True) if ctx.needs_input_grad[0] else None
+            ctx.prt = _image(wr, None, True) if ctx.needs_input_grad[0] else None
+            y = _gemm_nt(agg, _image(wl, wr, False), x, bl, n_out)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
         return y
@@ -392,15 +437,15 @@ class _SageConv(torch.autograd.Function):
             gwl, _ = _weight_grad(gt, x, wl)
             gwr, gb = _weight_grad(g, x, wr, bl, want_bias)
             if need[0]:
-                gx = _gemm_nt(gt, ctx.plt, g, ctx.prt, None, n_in)
+                gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
             gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
             gwr, _ = _weight_grad(g, x, wr)
             if need[0]:
-                t = _gemm_nt(g, ctx.plt, None, None, None, n_in)
-                gr = _gemm_nt(g, ctx.prt, None, None, None, n_in)
+                t = _gemm_nt(g, ctx.plt, None, None, n_in)
+                gr = _gemm_nt(g, ctx.prt, None, None, n_in)
                 gx = new_padded(n, n_in, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, t, n_in, 0, None, None, inv, gr, gx)
         return gx, gwl, gb, gwr, None, None

@@ -199,6 +199,19 @@ size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
                 int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
+/* ---- the same projections on the bf16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three
+ *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
+ * hgv_gemm_nt16_supported: 1 when the split image of an N x (K1 + K2) weight, whole or in two parts along N,
+ * fits in LDS (then hgv_pack16_bytes > 0).  hgv_pack16_weights builds the image of [W1 | W2] (W2 nullable,
+ * element (n,k) of source s at Ws[n*sn_s + k*sk_s]); hgv_gemm_nt16 computes C = A1 W1^T (+ A2 W2^T) (+ bias)
+ * under the contract of hgv_gemm_nt_packed (A, C 16-byte aligned, leading dimensions multiples of 4). */
+int hgv_gemm_nt16_supported(int N, int K1, int K2);
+size_t hgv_pack16_bytes(int N, int K1, int K2);
+int hgv_pack16_weights(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* W2, int64_t sn2, int64_t sk2, int K2,
+                       int N, void* out, hgv_stream_t stream);
+int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                  const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
+
 /* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
  *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------
  * hgv_adam_step: torch's Adam arithmetic (bias-corrected, eps added after the sqrt(v)/sqrt(1-b2^t) division,

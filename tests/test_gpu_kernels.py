@@ -424,8 +424,16 @@ GEMM_SHAPES = [  # (M, K1, K2, N)
 ]
 
 
+@pytest.fixture(params=["bf16x6", "fp32"])
+def projection_kind(request):
+    from hgvae_amd import functional as Fn
+    Fn.set_projection(request.param)
+    yield request.param
+    Fn.set_projection("bf16x6")
+
+
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
-def test_dual_linear_forward_backward(shape):
+def test_dual_linear_forward_backward(shape, projection_kind):
     """y = xa Wa^T + xb Wb^T + b on the MFMA kernels vs an fp64 CPU product (MFMA fp32 is an exact
     fma chain, so the error is the usual fp32 accumulation error ~1e-7 * sum|a b|)."""
     from hgvae_amd import functional as Fn
@@ -454,9 +462,10 @@ def test_dual_linear_forward_backward(shape):
         assert float(base[:, n:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("kind", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("shape", [(160_984, 138, 138, 138), (160_984, 105, 105, 138), (131_072 + 7, 138, None, 56),
                                    (70_001, 276, None, 138)])
-def test_projection_kernels_at_benchmark_rows(shape):
+def test_projection_kernels_at_benchmark_rows(shape, kind):
     """Row counts of the benchmark shard: every wave of the resident-weight kernel streams several
     row tiles (the load ring runs across tile boundaries) and the weight-gradient kernel splits the
     rows over ~680 slices plus the 1-4 leftover rows.  Checked against an fp64 product on the device
@@ -475,14 +484,20 @@ def test_projection_kernels_at_benchmark_rows(shape):
     w = torch.randn(n, k1 + (k2 or 0), generator=gen, device=dev())
     bias = torch.randn(n, generator=gen, device=dev())
     g = rnd(m, n)
-    pa, pb, pat = Fn._pack((w[:, :k1], False), (w[:, k1:], False) if k2 else None, (w[:, :k1], True))
-    y = Fn._gemm_nt(xa, pa, xb, pb, bias, n)
+    Fn.set_projection(kind)
+    try:
+        img = Fn._image(w[:, :k1], w[:, k1:] if k2 else None, False)
+        img_t = Fn._image(w[:, :k1], None, True)
+        assert img.kind == kind
+    finally:
+        Fn.set_projection("bf16x6")
+    y = Fn._gemm_nt(xa, img, xb, bias, n)
     ref = xa.double() @ w[:, :k1].double().t() + bias.double()
     if k2:
         ref = ref + xb.double() @ w[:, k1:].double().t()
     scale = float(ref.abs().max())
     assert float((y.double() - ref).abs().max()) <= 2e-6 * scale * (k1 + (k2 or 0)) ** 0.5
-    gx = Fn._gemm_nt(g, pat, None, None, None, k1)                        # grad-input product
+    gx = Fn._gemm_nt(g, img_t, None, None, k1)                            # grad-input product
     refx = g.double() @ w[:, :k1].double()
     assert float((gx.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max()) * n ** 0.5
     gw, gb = Fn._gemm_tn(g, xa, True)

@@ -24,8 +24,7 @@ def timeit(fn, iters=20):
 
 
 def nt_call(xa, wa, xb, wb, bias, n):
-    pa, pb = Fn._pack((wa, False), (wb, False) if xb is not None else None)
-    return Fn._gemm_nt(xa, pa, xb, pb, bias, n)
+    return Fn._gemm_nt(xa, Fn._image(wa, wb if xb is not None else None, False), xb, bias, n)
 
 
 def main():
