@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhgvae_hip.so")
+LIB_PATH = os.environ.get("HGVAE_LIB") or os.path.join(_HERE, "csrc", "libhgvae_hip.so")   # HGVAE_LIB: another build of the library
 
 _vp, _i64, _i32, _f32, _u64, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 

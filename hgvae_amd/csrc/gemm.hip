@@ -142,12 +142,19 @@ __global__ __launch_bounds__(1024) void k_gemm_nt_res(const ResArgs g) {
     {
         const int n1 = G1 * R, n2 = G2 * R;     // 16-byte pieces
         f32x4* dst = reinterpret_cast<f32x4*>(Wl);
-        const f32x4* w1 = reinterpret_cast<const f32x4*>(g.s[0].Wp);
-        for (int e = t; e < n1; e += blockDim.x) dst[e] = w1[e];
-        if (n2 > 0) {
-            const f32x4* w2 = reinterpret_cast<const f32x4*>(g.s[1].Wp);
-            for (int e = t; e < n2; e += blockDim.x) dst[n1 + e] = w2[e];
-        }
+        // batches of 8 loads in flight per thread: one load -> store per iteration would pay the L2 latency ~10 times
+        auto copy_image = [&](const f32x4* src, f32x4* to, int count) __attribute__((always_inline)) {
+            for (int e0 = t; e0 < count; e0 += 8 * blockDim.x) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * (int)blockDim.x, count - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * (int)blockDim.x < count) to[e0 + u * (int)blockDim.x] = v[u];
+            }
+        };
+        copy_image(reinterpret_cast<const f32x4*>(g.s[0].Wp), dst, n1);
+        if (n2 > 0) copy_image(reinterpret_cast<const f32x4*>(g.s[1].Wp), dst + n1, n2);
         for (int e = t; e < R; e += blockDim.x) bias_s[e] = (g.bias && e < g.N) ? g.bias[e] : 0.f;
         // Step table: for step fq of a tile and lane group kq, .x = byte offset of the A quad in its
         // row (bit 31 set: the quad is padding and counts as zero), .y = byte offset of the weight

@@ -125,7 +125,16 @@ __global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16A
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)part * img);
         f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
-        for (int e = t; e < (int)(img / 16); e += blockDim.x) dst[e] = src[e];
+        // batches of 8 loads in flight per thread: one load -> store per iteration would pay the L2 latency ~10 times
+        const int npieces = (int)(img / 16);
+        for (int e0 = t; e0 < npieces; e0 += 8 * blockDim.x) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * (int)blockDim.x, npieces - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * (int)blockDim.x < npieces) dst[e0 + u * (int)blockDim.x] = v[u];
+        }
         for (int e = t; e < g.chunks * 4; e += blockDim.x) {
             const int blk = e;                                     // chunk * 4 + kq
             int second = 0, col = 0; int64_t ld = a.lda1;
@@ -293,7 +302,7 @@ int cu_count16() {
 
 template <int NT>
 int launch_nt16(const Nt16Args& a, size_t lds, hipStream_t st) {
-    constexpr int RING = 3;
+    constexpr int RING = NT > 6 ? 3 : 4;
     auto kern = k_gemm_nt16<NT, RING>;
     static bool raised[64] = {false};
     int dev = 0;
