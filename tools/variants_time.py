@@ -47,6 +47,9 @@ def main():
         for _ in range(3):
             step()
         torch.cuda.synchronize()
+        import gc
+        gc.collect()
+        gc.freeze()
         t0 = time.perf_counter()
         n = 10
         for _ in range(n):
