@@ -68,12 +68,26 @@ struct Pack16Args {
     __bf16* out;
 };
 
-// one thread per (part, chunk, row, k) element of the image; writes the three pieces
-__global__ __launch_bounds__(256) void k_pack16(const Pack16Args a) {
+constexpr int PACK16_MAX_JOBS = 4;
+struct Pack16Jobs {
+    Pack16Args job[PACK16_MAX_JOBS];
+    int first_block[PACK16_MAX_JOBS + 1];    // job q owns blocks [first_block[q], first_block[q+1])
+    int njobs;
+};
+
+// one thread per (part, chunk, row, k) element of an image; writes the three pieces.  Up to four images per launch.
+__global__ __launch_bounds__(256) void k_pack16(const Pack16Jobs jobs) {
+    int q = 0;
+#pragma unroll
+    for (int j = 1; j < PACK16_MAX_JOBS; ++j)
+        if (j < jobs.njobs && (int)blockIdx.x >= jobs.first_block[j]) q = j;
+    const Pack16Args& a = jobs.job[q];
     const Geo16& g = a.g;
     const int64_t per_part = (int64_t)g.chunks * g.tpp * 16 * 32;
     const int64_t total = per_part * g.parts;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    {
+        const int64_t e = (int64_t)((int)blockIdx.x - jobs.first_block[q]) * blockDim.x + threadIdx.x;
+        if (e >= total) return;
         const int part = (int)(e / per_part);
         int64_t l = e - (int64_t)part * per_part;
         const int rows = g.tpp * 16;
@@ -96,26 +110,49 @@ __global__ __launch_bounds__(256) void k_pack16(const Pack16Args a) {
     }
 }
 
+int fill_pack16_job(Pack16Args& a, const float* W1, int64_t sn1, int64_t sk1, int K1, const float* W2, int64_t sn2, int64_t sk2,
+                    int K2, int N, void* out) {
+    HGV_REQUIRE(W1 && out && N > 0 && K1 > 0 && (W2 ? K2 > 0 : K2 == 0), HGV_EINVAL, "pack16_weights: bad arguments");
+    HGV_REQUIRE(geo16(N, K1, K2, &a.g), HGV_EUNSUPPORTED, "pack16_weights: %d x (%d + %d) does not fit in LDS", N, K1, K2);
+    HGV_REQUIRE(hgv_aligned(out, 16), HGV_EINVAL, "pack16_weights: output must be 16-byte aligned");
+    a.W1 = W1; a.sn1 = sn1; a.sk1 = sk1; a.W2 = W2; a.sn2 = sn2; a.sk2 = sk2; a.out = (__bf16*)out;
+    return HGV_OK;
+}
+
+int launch_pack16(Pack16Jobs& jobs, hipStream_t stream) {
+    int blocks = 0;
+    for (int q = 0; q < jobs.njobs; ++q) {
+        const Geo16& g = jobs.job[q].g;
+        jobs.first_block[q] = blocks;
+        blocks += (int)hgv_cdiv((int64_t)g.parts * g.chunks * g.tpp * 16 * 32, 256);
+    }
+    for (int q = jobs.njobs; q <= PACK16_MAX_JOBS; ++q) jobs.first_block[q] = blocks;
+    hipLaunchKernelGGL(k_pack16, dim3((unsigned)blocks), dim3(256), 0, stream, jobs);
+    HGV_CHECK_LAUNCH("pack16_weights");
+    return HGV_OK;
+}
+
 struct Nt16Args {
     const float* A1; int64_t lda1; const float* A2; int64_t lda2;
     Geo16 g;
     const __bf16* Wp; const float* bias;
     float* C; int64_t ldc; int64_t M;
     int64_t ntiles;            // 16-row tiles
-    int part;                  // which part of the image this launch multiplies by (NT = its n tiles, exactly)
+    int wgs0;                  // two-part launches: workgroups [0, wgs0) work on part 0, the rest on part 1
 };
 
 // waves per workgroup: 16 while the registers allow 4 waves per SIMD (<= 128 VGPRs), 12 for the widest parts
 template <int NT> constexpr int nt16_waves() { return NT > 6 ? 12 : 16; }
 
+template <int NT> constexpr int nt16_ring() { return NT > 6 ? 3 : 4; }
+
+// The work of one workgroup: part `part` of the image (exactly NT n tiles) times the row tiles
+// wg_rank, wg_rank + wgs, ... (dealt to its waves).
 template <int NT, int RING>
-__global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16Args a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
     const Geo16& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
     const int wib = __builtin_amdgcn_readfirstlane(t >> 6), wpb = blockDim.x >> 6;
-    const int part = a.part;
-    const int wg_rank = blockIdx.x, wgs = gridDim.x;
     const int t0 = part * g.tpp;                                   // first n tile of the part; it holds exactly NT tiles
     const int rows = g.tpp * 16;                                   // rows per piece image (parts are stored with tpp tiles)
     __bf16* Wl = reinterpret_cast<__bf16*>(lds_raw);
@@ -289,6 +326,22 @@ __global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16A
     }
 }
 
+// One part per launch (the whole weight, or one part of a weight split along N).
+template <int NT>
+__global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16Args a, const int part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    nt16_body<NT, nt16_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
+}
+
+// Both parts of a weight split along N in one launch: the first a.wgs0 workgroups keep part 0
+// (NT0 n tiles) resident, the others part 1 (NT1 = NT0 or NT0 - 1 tiles); each group streams all rows of A.
+template <int NT0, int NT1>
+__global__ __launch_bounds__(64 * nt16_waves<NT0>()) void k_gemm_nt16_pair(const Nt16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if ((int)blockIdx.x < a.wgs0) nt16_body<NT0, nt16_ring<NT0>()>(a, lds_raw, 0, blockIdx.x, a.wgs0);
+    else nt16_body<NT1, nt16_ring<NT1>()>(a, lds_raw, 1, (int)blockIdx.x - a.wgs0, (int)gridDim.x - a.wgs0);
+}
+
 int cu_count16() {
     static int cached[64] = {0};
     int dev = 0;
@@ -300,11 +353,9 @@ int cu_count16() {
     return cached[dev];
 }
 
-template <int NT>
-int launch_nt16(const Nt16Args& a, size_t lds, hipStream_t st) {
-    constexpr int RING = NT > 6 ? 3 : 4;
-    auto kern = k_gemm_nt16<NT, RING>;
-    static bool raised[64] = {false};
+template <typename Kern>
+int raise_lds16(Kern kern) {
+    static bool raised[64] = {false};          // one instance per kernel type
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!raised[dev]) {
@@ -313,6 +364,14 @@ int launch_nt16(const Nt16Args& a, size_t lds, hipStream_t st) {
         HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "gemm_nt16: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
         raised[dev] = true;
     }
+    return HGV_OK;
+}
+
+template <int NT>
+int launch_nt16(const Nt16Args& a, int part, size_t lds, hipStream_t st) {
+    auto kern = k_gemm_nt16<NT>;
+    const int rc = raise_lds16(kern);
+    if (rc != HGV_OK) return rc;
     // one workgroup per compute unit; as many waves (<= 16) as there are tiles to hand out
     const int cus = cu_count16();
     int64_t wpb = hgv_cdiv(a.ntiles, cus);
@@ -320,22 +379,55 @@ int launch_nt16(const Nt16Args& a, size_t lds, hipStream_t st) {
     if (wpb < 1) wpb = 1;
     int64_t blocks = hgv_cdiv(a.ntiles, wpb);
     if (blocks > cus) blocks = cus;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), lds, st, a, part);
     return HGV_OK;
 }
 
-int launch_nt16_part(const Nt16Args& a, int nt, size_t lds, hipStream_t st) {
+int launch_nt16_part(const Nt16Args& a, int part, int nt, size_t lds, hipStream_t st) {
     switch (nt) {
-        case 1: return launch_nt16<1>(a, lds, st);
-        case 2: return launch_nt16<2>(a, lds, st);
-        case 3: return launch_nt16<3>(a, lds, st);
-        case 4: return launch_nt16<4>(a, lds, st);
-        case 5: return launch_nt16<5>(a, lds, st);
-        case 6: return launch_nt16<6>(a, lds, st);
-        case 7: return launch_nt16<7>(a, lds, st);
-        case 8: return launch_nt16<8>(a, lds, st);
-        default: return launch_nt16<9>(a, lds, st);
+        case 1: return launch_nt16<1>(a, part, lds, st);
+        case 2: return launch_nt16<2>(a, part, lds, st);
+        case 3: return launch_nt16<3>(a, part, lds, st);
+        case 4: return launch_nt16<4>(a, part, lds, st);
+        case 5: return launch_nt16<5>(a, part, lds, st);
+        case 6: return launch_nt16<6>(a, part, lds, st);
+        case 7: return launch_nt16<7>(a, part, lds, st);
+        case 8: return launch_nt16<8>(a, part, lds, st);
+        default: return launch_nt16<9>(a, part, lds, st);
     }
+}
+
+// Both parts in one launch.  The compute units are shared out in proportion to the parts' n tiles
+// (every part streams all row tiles, so its work is proportional to its width).
+template <int NT0, int NT1>
+int launch_nt16_pair(Nt16Args a, size_t lds, hipStream_t st) {
+    auto kern = k_gemm_nt16_pair<NT0, NT1>;
+    const int rc = raise_lds16(kern);
+    if (rc != HGV_OK) return rc;
+    const int cus = cu_count16();
+    int share0 = (cus * NT0 + (NT0 + NT1) / 2) / (NT0 + NT1);
+    if (share0 < 1) share0 = 1;
+    if (share0 > cus - 1) share0 = cus - 1;
+    const int share1 = cus - share0;
+    int64_t wpb = hgv_cdiv(a.ntiles, share1 < share0 ? share1 : share0);
+    if (wpb > nt16_waves<NT0>()) wpb = nt16_waves<NT0>();
+    if (wpb < 1) wpb = 1;
+    const int64_t want = hgv_cdiv(a.ntiles, wpb);
+    const int wgs0 = (int)(want < share0 ? want : share0), wgs1 = (int)(want < share1 ? want : share1);
+    a.wgs0 = wgs0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wgs0 + wgs1)), dim3((unsigned)(64 * wpb)), lds, st, a);
+    return HGV_OK;
+}
+
+// n tiles of the two parts are (tpp, tpp) or (tpp, tpp - 1)
+int launch_nt16_both(const Nt16Args& a, int nt0, int nt1, size_t lds, hipStream_t st) {
+#define HGV_PAIR(N0)                                                                                   \
+    case N0: return nt1 == N0 ? launch_nt16_pair<N0, N0>(a, lds, st) : launch_nt16_pair<N0, (N0 > 1 ? N0 - 1 : 1)>(a, lds, st);
+    switch (nt0) {
+        HGV_PAIR(1) HGV_PAIR(2) HGV_PAIR(3) HGV_PAIR(4) HGV_PAIR(5) HGV_PAIR(6) HGV_PAIR(7) HGV_PAIR(8) HGV_PAIR(9)
+        default: return HGV_EUNSUPPORTED;
+    }
+#undef HGV_PAIR
 }
 
 }  // namespace
@@ -355,15 +447,26 @@ extern "C" size_t hgv_pack16_bytes(int N, int K1, int K2) {
 // Split-bf16 image of [W1 | W2] (W2 nullable): element (n,k) of source s at Ws[n*sn_s + k*sk_s].
 extern "C" int hgv_pack16_weights(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* W2, int64_t sn2, int64_t sk2,
                                   int K2, int N, void* out, hipStream_t stream) {
-    HGV_REQUIRE(W1 && out && N > 0 && K1 > 0 && (W2 ? K2 > 0 : K2 == 0), HGV_EINVAL, "pack16_weights: bad arguments");
-    Pack16Args a{};
-    HGV_REQUIRE(geo16(N, K1, K2, &a.g), HGV_EUNSUPPORTED, "pack16_weights: %d x (%d + %d) does not fit in LDS", N, K1, K2);
-    HGV_REQUIRE(hgv_aligned(out, 16), HGV_EINVAL, "pack16_weights: output must be 16-byte aligned");
-    a.W1 = W1; a.sn1 = sn1; a.sk1 = sk1; a.W2 = W2; a.sn2 = sn2; a.sk2 = sk2; a.out = (__bf16*)out;
-    const int64_t total = (int64_t)a.g.parts * a.g.chunks * a.g.tpp * 16 * 32;
-    hipLaunchKernelGGL(k_pack16, dim3((unsigned)hgv_cdiv(total, 256)), dim3(256), 0, stream, a);
-    HGV_CHECK_LAUNCH("pack16_weights");
-    return HGV_OK;
+    Pack16Jobs jobs{};
+    jobs.njobs = 1;
+    const int rc = fill_pack16_job(jobs.job[0], W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, out);
+    if (rc != HGV_OK) return rc;
+    return launch_pack16(jobs, stream);
+}
+
+// Up to four images in one launch: job q packs [W1[q] | W2[q]] (W2[q] may be null, then K2[q] = 0) into out[q].
+extern "C" int hgv_pack16_weights_multi(int njobs, const float* const* W1, const int64_t* sn1, const int64_t* sk1, const int* K1,
+                                        const float* const* W2, const int64_t* sn2, const int64_t* sk2, const int* K2,
+                                        const int* N, void* const* out, hipStream_t stream) {
+    HGV_REQUIRE(njobs >= 1 && njobs <= PACK16_MAX_JOBS && W1 && sn1 && sk1 && K1 && W2 && sn2 && sk2 && K2 && N && out, HGV_EINVAL,
+                "pack16_weights_multi: 1..%d jobs and non-null arrays expected", PACK16_MAX_JOBS);
+    Pack16Jobs jobs{};
+    jobs.njobs = njobs;
+    for (int q = 0; q < njobs; ++q) {
+        const int rc = fill_pack16_job(jobs.job[q], W1[q], sn1[q], sk1[q], K1[q], W2[q], sn2[q], sk2[q], K2[q], N[q], out[q]);
+        if (rc != HGV_OK) return rc;
+    }
+    return launch_pack16(jobs, stream);
 }
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the split-bf16 image.  A1/A2: 16-byte aligned, lda % 4 == 0,
@@ -382,13 +485,16 @@ extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float*
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const __bf16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
     const size_t lds = part_bytes16(a.g.tpp, a.g.chunks) + (size_t)a.g.chunks * 64 + 9 * 16 * 4;
-    // one launch per part (a part holds exactly its n tiles; the rows of A are streamed once per part)
-    for (int part = 0; part < a.g.parts; ++part) {
-        a.part = part;
-        const int nt = part + 1 < a.g.parts ? a.g.tpp : a.g.tiles - part * a.g.tpp;
-        const int rc = launch_nt16_part(a, nt, lds, stream);
-        if (rc != HGV_OK) return rc;
+    // a part holds exactly its n tiles; the rows of A are streamed once per part
+    int rc;
+    if (a.g.parts == 1) {
+        rc = launch_nt16_part(a, 0, a.g.tiles, lds, stream);
+    } else {
+        const int nt1 = a.g.tiles - a.g.tpp;
+        HGV_REQUIRE(nt1 >= 1 && (nt1 == a.g.tpp || nt1 == a.g.tpp - 1), HGV_EUNSUPPORTED, "gemm_nt16: unexpected split %d + %d", a.g.tpp, nt1);
+        rc = launch_nt16_both(a, a.g.tpp, nt1, lds, stream);
     }
+    if (rc != HGV_OK) return rc;
     HGV_CHECK_LAUNCH("gemm_nt16");
     return HGV_OK;
 }

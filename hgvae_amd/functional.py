@@ -183,23 +183,59 @@ class _Image:
         self.kind, self.a, self.b = kind, a, b
 
 
-def _image(wa: torch.Tensor, wb: Optional[torch.Tensor], transposed: bool) -> _Image:
-    """Weight image for ``x_a @ op(wa)^T (+ x_b @ op(wb)^T)`` with op(w) = w or, with ``transposed``,
-    w^T (the grad-input product).  Built at every use (see :func:`_pack`)."""
+def _images(*specs) -> list:
+    """Weight images for ``x_a @ op(wa)^T (+ x_b @ op(wb)^T)``: ``specs`` are ``(wa, wb, transposed)``
+    triples (None entries are skipped and returned as None) with op(w) = w or, with ``transposed``,
+    w^T (the grad-input product).  All images an operator needs are built by one launch per kind,
+    at every use (see :func:`_pack`)."""
+    import ctypes as C
     lib = _lib.load()
-    n, k1 = (wa.size(1), wa.size(0)) if transposed else (wa.size(0), wa.size(1))
-    k2 = 0 if wb is None else (wb.size(0) if transposed else wb.size(1))
-    if _projection == "bf16x6" and lib.hgv_gemm_nt16_supported(n, k1, k2):
-        buf = torch.empty(lib.hgv_pack16_bytes(n, k1, k2) // 4, dtype=torch.float32, device=wa.device)
+    out = [None] * len(specs)
+    split, plain = [], []
+    for i, sp in enumerate(specs):
+        if sp is None:
+            continue
+        wa, wb, t = sp
+        n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
+        k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
+        if _projection == "bf16x6" and lib.hgv_gemm_nt16_supported(n, k1, k2):
+            split.append((i, wa, wb, t, n, k1, k2))
+        else:
+            plain.append((i, wa, wb, t))
+    for j0 in range(0, len(split), 4):
+        jobs = split[j0:j0 + 4]
+        nj = len(jobs)
+        sizes = [lib.hgv_pack16_bytes(n, k1, k2) // 4 for (_, _, _, _, n, k1, k2) in jobs]
+        buf = torch.empty(sum(sizes), dtype=torch.float32, device=jobs[0][1].device)
+        W1, W2, Op = (C.c_void_p * nj)(), (C.c_void_p * nj)(), (C.c_void_p * nj)()
+        sn1, sk1, sn2, sk2 = (C.c_int64 * nj)(), (C.c_int64 * nj)(), (C.c_int64 * nj)(), (C.c_int64 * nj)()
+        K1, K2, N = (C.c_int * nj)(), (C.c_int * nj)(), (C.c_int * nj)()
+        off = 0
+        for q, ((i, wa, wb, t, n, k1, k2), sz) in enumerate(zip(jobs, sizes)):
+            piece = buf[off:off + sz]
+            off += sz
+            out[i] = _Image("bf16x6", piece)
+            W1[q], Op[q] = wa.data_ptr(), piece.data_ptr()
+            sn1[q], sk1[q] = (wa.stride(1), wa.stride(0)) if t else (wa.stride(0), wa.stride(1))
+            if wb is not None:
+                W2[q] = wb.data_ptr()
+                sn2[q], sk2[q] = (wb.stride(1), wb.stride(0)) if t else (wb.stride(0), wb.stride(1))
+            K1[q], K2[q], N[q] = k1, k2, n
+        _lib.call("hgv_pack16_weights_multi", nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
+    # fp32 images: two weights per image at most, four weights per launch
+    flat = [(i, which, w, t) for (i, wa, wb, t) in plain for (which, w) in (("a", wa), ("b", wb)) if w is not None]
+    packed = {}
+    for j0 in range(0, len(flat), 4):
+        group = flat[j0:j0 + 4]
+        for (i, which, _, _), pk in zip(group, _pack(*[(w, t) for (_, _, w, t) in group])):
+            packed[(i, which)] = pk
+    for (i, wa, wb, t) in plain:
+        out[i] = _Image("fp32", packed[(i, "a")], packed.get((i, "b")))
+    return out
 
-        def st(w):
-            return (w.stride(1), w.stride(0)) if transposed else (w.stride(0), w.stride(1))
-        sa, sb = st(wa), (st(wb) if wb is not None else (0, 0))
-        _lib.call("hgv_pack16_weights", wa.data_ptr(), sa[0], sa[1], k1, _lib.ptr(wb), sb[0], sb[1], k2, n,
-                  buf.data_ptr(), _lib.stream())
-        return _Image("bf16x6", buf)
-    pa, pb = _pack((wa, transposed), (wb, transposed) if wb is not None else None)
-    return _Image("fp32", pa, pb)
+
+def _image(wa: torch.Tensor, wb: Optional[torch.Tensor], transposed: bool) -> _Image:
+    return _images((wa, wb, transposed))[0]
 
 
 def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
@@ -289,9 +325,10 @@ class _DualLinear(torch.autograd.Function):
         xa = as_padded(xa)
         xb = as_padded(xb) if xb is not None else None
         need = ctx.needs_input_grad
-        ctx.pat = _image(wa, None, True) if need[0] else None
-        ctx.pbt = _image(wb, None, True) if xb is not None and need[2] else None
-        y = _gemm_nt(xa, _image(wa, wb if xb is not None else None, False), xb, bias, wa.size(0))
+        fwd, ctx.pat, ctx.pbt = _images((wa, wb if xb is not None else None, False),
+                                        (wa, None, True) if need[0] else None,
+                                        (wb, None, True) if xb is not None and need[2] else None)
+        y = _gemm_nt(xa, fwd, xb, bias, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.save_for_backward(xa, wa, xb, wb, bias)
         return y
@@ -334,9 +371,9 @@ class _ConcatLinear(torch.autograd.Function):
         xa, xb = as_padded(xa), as_padded(xb)
         need = ctx.needs_input_grad
         wa, wb = w[:, :ka], w[:, ka:]
-        ctx.pat = _image(wa, None, True) if need[0] else None
-        ctx.pbt = _image(wb, None, True) if need[1] else None
-        y = _gemm_nt(xa, _image(wa, wb, False), xb, bias, w.size(0))
+        fwd, ctx.pat, ctx.pbt = _images((wa, wb, False), (wa, None, True) if need[0] else None,
+                                        (wb, None, True) if need[1] else None)
+        y = _gemm_nt(xa, fwd, xb, bias, w.size(0))
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xa, xb, w, bias)
         return y
@@ -413,9 +450,9 @@ class _SageConv(torch.autograd.Function):
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
-            ctx.plt = _image(wl, None, True) if ctx.needs_input_grad[0] else None
-            ctx.prt = _image(wr, None, True) if ctx.needs_input_grad[0] else None
-            y = _gemm_nt(agg, _image(wl, wr, False), x, bl, n_out)
+            gi = ctx.needs_input_grad[0]
+            fwd, ctx.plt, ctx.prt = _images((wl, wr, False), (wl, None, True) if gi else None, (wr, None, True) if gi else None)
+            y = _gemm_nt(agg, fwd, x, bl, n_out)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
         return y

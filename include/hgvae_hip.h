@@ -203,12 +203,17 @@ int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda,
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
  * hgv_gemm_nt16_supported: 1 when the split image of an N x (K1 + K2) weight, whole or in two parts along N,
  * fits in LDS (then hgv_pack16_bytes > 0).  hgv_pack16_weights builds the image of [W1 | W2] (W2 nullable,
- * element (n,k) of source s at Ws[n*sn_s + k*sk_s]); hgv_gemm_nt16 computes C = A1 W1^T (+ A2 W2^T) (+ bias)
- * under the contract of hgv_gemm_nt_packed (A, C 16-byte aligned, leading dimensions multiples of 4). */
+ * element (n,k) of source s at Ws[n*sn_s + k*sk_s]); hgv_pack16_weights_multi builds up to four images in one
+ * launch (arrays of njobs entries; W2[q] may be null with K2[q] = 0); hgv_gemm_nt16 computes
+ * C = A1 W1^T (+ A2 W2^T) (+ bias) under the contract of hgv_gemm_nt_packed (A, C 16-byte aligned, leading
+ * dimensions multiples of 4) in one launch, whether the image has one part or two. */
 int hgv_gemm_nt16_supported(int N, int K1, int K2);
 size_t hgv_pack16_bytes(int N, int K1, int K2);
 int hgv_pack16_weights(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* W2, int64_t sn2, int64_t sk2, int K2,
                        int N, void* out, hgv_stream_t stream);
+int hgv_pack16_weights_multi(int njobs, const float* const* W1, const int64_t* sn1, const int64_t* sk1, const int* K1,
+                             const float* const* W2, const int64_t* sn2, const int64_t* sk2, const int* K2, const int* N,
+                             void* const* out, hgv_stream_t stream);
 int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                   const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
 
