@@ -397,21 +397,32 @@ int launch_nt16_part(const Nt16Args& a, int part, int nt, size_t lds, hipStream_
     }
 }
 
-// Both parts in one launch.  The compute units are shared out in proportion to the parts' n tiles
-// (every part streams all row tiles, so its work is proportional to its width).
+// Both parts in one launch; every part streams all row tiles of A.
 template <int NT0, int NT1>
 int launch_nt16_pair(Nt16Args a, size_t lds, hipStream_t st) {
     auto kern = k_gemm_nt16_pair<NT0, NT1>;
     const int rc = raise_lds16(kern);
     if (rc != HGV_OK) return rc;
     const int cus = cu_count16();
-    int share0 = (cus * NT0 + (NT0 + NT1) / 2) / (NT0 + NT1);
-    if (share0 < 1) share0 = 1;
-    if (share0 > cus - 1) share0 = cus - 1;
-    const int share1 = cus - share0;
-    int64_t wpb = hgv_cdiv(a.ntiles, share1 < share0 ? share1 : share0);
+    int64_t wpb = hgv_cdiv(a.ntiles, cus / 2 > 0 ? cus / 2 : 1);
     if (wpb > nt16_waves<NT0>()) wpb = nt16_waves<NT0>();
     if (wpb < 1) wpb = 1;
+    // Share of the compute units per part: a wave's time is (rounds of row tiles) x (cost of one row
+    // tile), and the cost grows slowly with the part's width (measured: 33 / 36 / 44 us for 4 / 5 / 9
+    // n tiles, i.e. ~ 11 + NT), so the split that minimises the slower part is near even and is
+    // decided by the rounding of the rounds.  Ties go to the split closest to even.
+    int share0 = cus / 2;
+    {
+        int64_t best = -1;
+        for (int s0 = cus / 4 > 0 ? cus / 4 : 1; s0 <= cus - (cus / 4 > 0 ? cus / 4 : 1) && s0 < cus; ++s0) {
+            const int64_t r0 = hgv_cdiv(a.ntiles, (int64_t)s0 * wpb), r1 = hgv_cdiv(a.ntiles, (int64_t)(cus - s0) * wpb);
+            const int64_t c0 = r0 * (11 + NT0), c1 = r1 * (11 + NT1);
+            const int64_t c = c0 > c1 ? c0 : c1;
+            const int d = s0 > cus / 2 ? s0 - cus / 2 : cus / 2 - s0, dbest = share0 > cus / 2 ? share0 - cus / 2 : cus / 2 - share0;
+            if (best < 0 || c < best || (c == best && d < dbest)) { best = c; share0 = s0; }
+        }
+    }
+    const int share1 = cus - share0;
     const int64_t want = hgv_cdiv(a.ntiles, wpb);
     const int wgs0 = (int)(want < share0 ? want : share0), wgs1 = (int)(want < share1 ? want : share1);
     a.wgs0 = wgs0;

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the fp32 MFMA projection kernels on the benchmark shapes (events on the launching stream)."""
+"""Times the projection kernels (HGVAE_PROJECTION = bf16x6 | fp32) and the weight-gradient kernel on the
+benchmark shapes (events on the launching stream; weight images are built outside the timed calls)."""
 import os
 import sys
 
@@ -23,8 +24,8 @@ def timeit(fn, iters=20):
     return ts[len(ts) // 2]
 
 
-def nt_call(xa, wa, xb, wb, bias, n):
-    return Fn._gemm_nt(xa, Fn._image(wa, wb if xb is not None else None, False), xb, bias, n)
+def nt_call(xa, img, xb, bias, n):
+    return Fn._gemm_nt(xa, img, xb, bias, n)
 
 
 def main():
@@ -43,11 +44,12 @@ def main():
         wa, wb = w[:, :k1], (w[:, k1:] if k2 else None)
         bias = torch.randn(n, device=dev)
         g = new_padded(m, n, dev); g.normal_()
-        t_nt = 1.0 if os.environ.get("TN_ONLY") else timeit(lambda: nt_call(xa, wa, xb, wb, bias, n))
+        img = Fn._image(wa, wb if xb is not None else None, False)
+        t_nt = 1.0 if os.environ.get("TN_ONLY") else timeit(lambda: nt_call(xa, img, xb, bias, n))
         fl = 2.0 * m * (k1 + (k2 or 0)) * n
         t_tn = timeit(lambda: Fn._gemm_tn(g, xa, True))
         fl_tn = 2.0 * m * n * k1
-        print(f"NT M={m} K=({k1},{k2}) N={n}: {t_nt:7.1f} us {fl / t_nt / 1e6:6.1f} TF/s | "
+        print(f"NT[{img.kind}] M={m} K=({k1},{k2}) N={n}: {t_nt:7.1f} us {fl / t_nt / 1e6:6.1f} TF/s | "
               f"TN N={n} K={k1}: {t_tn:7.1f} us {fl_tn / t_tn / 1e6:6.1f} TF/s", flush=True)
 
 
