@@ -409,16 +409,6 @@ def concat_linear(xa, xb, w, bias=None):
     return _ConcatLinear.apply(xa, xb, w, bias)
 
 
-def _packed_stack(wl: torch.Tensor, wr: torch.Tensor) -> torch.Tensor:
-    """Packed image of [wl ; wr] stacked along the output dimension (both [n_out, K]); built at every use."""
-    n, k = wl.size(0), wl.size(1)
-    buf = torch.zeros(_lib.load().hgv_pack_bytes(2 * n, k) // 4, dtype=torch.float32, device=wl.device)
-    for w, off in ((wl, 0), (wr, n)):
-        _lib.call("hgv_pack_weight_rows", w.data_ptr(), w.stride(0), w.stride(1), n, k, buf.data_ptr(), off,
-                  2 * n, _lib.stream())
-    return buf
-
-
 class _SageConv(torch.autograd.Function):
     """y = lin_l(aggregate(x)) + lin_r(x) as one operator (SAGEConv / GraphConv).
 
@@ -438,20 +428,25 @@ class _SageConv(torch.autograd.Function):
         x = as_padded(x)
         n = graph.num_nodes
         first = n_out < n_in and 2 * n_out <= MAX_GEMM_N
+        gi = ctx.needs_input_grad[0]
+        ctx.pt = ctx.plt = ctx.prt = None
         if first:
-            tr = new_padded(n, 2 * n_out, x.device, zero_pad=False)
             bias2 = torch.cat([torch.zeros_like(bl), bl]) if bl is not None else None
-            _lib.call("hgv_gemm_nt_packed", x.data_ptr(), ld_of(x), n_in, _packed_stack(wl, wr).data_ptr(), None, 0, 0,
-                      None, _lib.ptr(bias2), n, 2 * n_out, tr.data_ptr(), ld_of(tr), _lib.stream())
+            stacked, ctx.pt = _images((torch.cat([wl, wr]), None, False), (wl, wr, True) if gi else None)   # gx = gt wl + g wr
+            tr = _gemm_nt(x, stacked, None, bias2, 2 * n_out)
             y = new_padded(n, n_out, x.device)
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
-            ctx.pt = _image(wl, wr, True) if ctx.needs_input_grad[0] else None     # gx = gt wl + g wr
             ctx.save_for_backward(x, wl, wr, bl)
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
-            gi = ctx.needs_input_grad[0]
-            fwd, ctx.plt, ctx.prt = _images((wl, wr, False), (wl, None, True) if gi else None, (wr, None, True) if gi else None)
+            # Input gradient: aggregate the output gradient first when that is not the wider side
+            # (gx = aggT(g) wl + g wr: one K-concatenated product), else project first (two products,
+            # the add fused into the aggregation).
+            if gi and n_out <= n_in:
+                fwd, ctx.pt = _images((wl, wr, False), (wl, wr, True))
+            else:
+                fwd, ctx.plt, ctx.prt = _images((wl, wr, False), (wl, None, True) if gi else None, (wr, None, True) if gi else None)
             y = _gemm_nt(agg, fwd, x, bl, n_out)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
@@ -480,7 +475,11 @@ class _SageConv(torch.autograd.Function):
             n_out, n_in = wl.shape
             gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
             gwr, _ = _weight_grad(g, x, wr)
-            if need[0]:
+            if need[0] and ctx.pt is not None:
+                gt = new_padded(n, n_out, g.device, zero_pad=False)
+                _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
+                gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
+            elif need[0]:
                 t = _gemm_nt(g, ctx.plt, None, None, n_in)
                 gr = _gemm_nt(g, ctx.prt, None, None, n_in)
                 gx = new_padded(n, n_in, g.device, zero_pad=False)
