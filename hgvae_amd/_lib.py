@@ -63,6 +63,9 @@ SIGNATURES = {
     "hgv_grad_norm_clip": (C.c_int, [_vp, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
     "hgv_gemm_tn_ws": (_sz, [_i64, _i32, _i32]),
     "hgv_gemm_tn": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
+    "hgv_gemm_tn2_ws": (_sz, [_i64, _i32, _i32, _i32]),
+    "hgv_gemm_tn2": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32,
+                               _vp, _sz, _vp]),
     "hgv_loss_ws": (_sz, []),
     "hgv_reparam_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _u64, _u64, _vp, _vp, _i64, _vp, _vp]),
     "hgv_reparam_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),

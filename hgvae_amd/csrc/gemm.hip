@@ -419,6 +419,8 @@ __global__ __launch_bounds__(256, MINW) void k_gemm_nt(const GemmArgs g) {
 struct TdArgs {
     const float* G; int64_t ldg; int N;
     const float* A; int64_t lda; int K;
+    const float* A2; int64_t lda2; int K2;   // optional second source: k blocks [kblk1, kblk) take their columns from A2
+    int kblk1;
     int64_t Mf;                 // rows covered here: 4*floor((M-1)/4)
     int64_t rows_per_slice;     // rows per wave, multiple of 4
     int sets;                   // workgroup slices = partial tile sets
@@ -449,7 +451,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
     const int set = (idx / per) * 8 + xcd, blk = idx % per;
     if (set >= g.sets) return;                       // whole workgroup: no barrier is skipped by part of it
     const int zb = blk / g.kblk, yb = blk - zb * g.kblk;
-    const int k0 = yb * 16 * WK + WK * i;
+    const bool second = yb >= g.kblk1;               // workgroup-uniform
+    const int k0 = (second ? yb - g.kblk1 : yb) * 16 * WK + WK * i;
+    const int Ks = second ? g.K2 : g.K;
+    const int64_t ldas = second ? g.lda2 : g.lda;
     const int64_t m_lo = min(g.Mf, ((int64_t)set * spw + w) * g.rows_per_slice);
     const int64_t m_hi = min(g.Mf, m_lo + g.rows_per_slice);
     // Per-lane byte offsets inside a 4-row step (constant for the whole kernel); the step's base
@@ -460,9 +465,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
         const int n0 = (zb * NB + b) * 16 * WN + WN * i;
         goff[b] = (uint32_t)(((int64_t)kq * g.ldg + (n0 < g.N ? n0 : 0)) * 4);
     }
-    const uint32_t aoff = (uint32_t)(((int64_t)kq * g.lda + (k0 < g.K ? k0 : 0)) * 4);
+    const uint32_t aoff = (uint32_t)(((int64_t)kq * ldas + (k0 < Ks ? k0 : 0)) * 4);
     const char* gbytes = reinterpret_cast<const char*>(g.G);
-    const char* abytes = reinterpret_cast<const char*>(g.A);
+    const char* abytes = reinterpret_cast<const char*>(second ? g.A2 : g.A);
 
     f32x4 acc[TN_][WK];
 #pragma unroll
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
             gr[d][b] = *reinterpret_cast<const typename TdVec<WN>::U*>(gbytes + r0 * g.ldg * 4 + goff[b]);
-        ar[d] = *reinterpret_cast<const typename TdVec<WK>::U*>(abytes + r0 * g.lda * 4 + aoff);
+        ar[d] = *reinterpret_cast<const typename TdVec<WK>::U*>(abytes + r0 * ldas * 4 + aoff);
         lm += 4;
     };
     const int steps = (int)((m_hi - m_lo) >> 2);                 // slices hold whole steps
@@ -576,6 +581,8 @@ struct TrArgs {
     int64_t ldg, lda; int n_last;                   // 1..4 such rows
     int N, K;
     float* GW; int64_t ldgw; float* gbias;
+    const float* a_last2; int64_t lda2; int K2; int kblk1;   // second source (k blocks >= kblk1) and its output matrix
+    float* GW2; int64_t ldgw2;
     int accumulate;                                 // add to GW / gbias instead of overwriting them
 };
 
@@ -622,10 +629,13 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
             const int b = rr / g.wn, r = rr - b * g.wn;
             const int zb = blk / g.kblk, yb = blk - zb * g.kblk;
             const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (4 * (lane >> 4) + q) + r;
-            const int k = yb * 16 * g.wk + g.wk * (lane & 15) + c;
-            if (n < g.N && k < g.K) {
-                for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)g.a_last[q2 * g.lda + k];
-                float* dst = g.GW + (int64_t)n * g.ldgw + k;
+            const bool second = yb >= g.kblk1;
+            const int k = (second ? yb - g.kblk1 : yb) * 16 * g.wk + g.wk * (lane & 15) + c;
+            if (n < g.N && k < (second ? g.K2 : g.K)) {
+                const float* al = second ? g.a_last2 : g.a_last;
+                const int64_t ldl = second ? g.lda2 : g.lda;
+                for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)al[q2 * ldl + k];
+                float* dst = second ? g.GW2 + (int64_t)n * g.ldgw2 + k : g.GW + (int64_t)n * g.ldgw + k;
                 *dst = g.accumulate ? *dst + (float)v : (float)v;
             }
         }
@@ -703,13 +713,14 @@ int td_width(int n, int wmax) {
 }
 
 struct TdPlan {
-    int wn, nb, wk, ngrp, kblk;      // tile shape per wave and block counts
+    int wn, nb, wk, ngrp, kblk;      // tile shape per wave and block counts (kblk over both sources)
+    int kblk1;                       // k blocks of the first source
     int sets, spw;                   // workgroups along the rows, waves per workgroup
     int64_t rows_per_slice;          // rows per wave
     int64_t tile_elems, bias_elems;  // floats per partial set
 };
 
-TdPlan td_plan(int64_t M, int N, int K) {
+TdPlan td_plan(int64_t M, int N, int K, int K2 = 0) {
     TdPlan p{};
     p.wn = td_width(N, 4);
     const int nblk = (int)hgv_cdiv(N, 16 * p.wn);
@@ -717,9 +728,10 @@ TdPlan td_plan(int64_t M, int N, int K) {
     int wkmax = 27 / (p.nb * p.wn);
     if (wkmax > 4) wkmax = 4;
     if (wkmax < 2 && p.nb > 1) { p.nb = 1; wkmax = 4; }       // very wide N: one block per wave, wide k
-    p.wk = td_width(K, wkmax);
+    p.wk = td_width(K > K2 ? K : K2, wkmax);
     p.ngrp = (int)hgv_cdiv(nblk, p.nb);
-    p.kblk = (int)hgv_cdiv(K, 16 * p.wk);
+    p.kblk1 = (int)hgv_cdiv(K, 16 * p.wk);
+    p.kblk = p.kblk1 + (K2 > 0 ? (int)hgv_cdiv(K2, 16 * p.wk) : 0);
     const int tn = p.nb * p.wn;
     p.tile_elems = (int64_t)p.ngrp * p.kblk * tn * p.wk * 256;
     p.bias_elems = (int64_t)p.ngrp * tn * 16;
@@ -896,25 +908,26 @@ extern "C" int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W
     return hgv_gemm_nt_packed(A1, lda1, K1, p1, A2, lda2, K2, A2 ? p2 : nullptr, bias, M, N, C, ldc, stream);
 }
 
-extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 256;
-    const TdPlan p = td_plan(M, N, K);
+namespace {
+
+size_t tn_ws_bytes(int64_t M, int N, int K1, int K2) {
+    if (M <= 0 || N <= 0 || K1 <= 0) return 256;
+    const TdPlan p = td_plan(M, N, K1, K2);
     const size_t sets = p.sets > 0 ? p.sets : 1;
     return hgv_align256(sets * p.tile_elems * 4) + hgv_align256(sets * p.bias_elems * 4);
 }
 
-// GW[N,K] (row-major, leading dimension ldgw >= K) (+)= G[M,N]^T A[M,K];  gbias[N] (+)= column sums of G (nullable).
-// accumulate != 0 adds to GW / gbias (gradient accumulation into an existing .grad buffer) instead of overwriting.
-// G and A are row-major with leading dimensions >= their widths (any 4-byte aligned pointers).
-extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M,
-                           float* GW, int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes,
-                           hipStream_t stream) {
+int gemm_tn_impl(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, float* GW, int64_t ldgw,
+                 const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
+                 void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(M > 0 && N > 0 && K > 0, HGV_EINVAL, "gemm_tn: bad sizes");
     HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K && ldgw >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
+    if (A2) HGV_REQUIRE(K2 > 0 && GW2 && lda2 >= K2 && ldgw2 >= K2 && lda2 < (1 << 27), HGV_EINVAL, "gemm_tn: bad second source");
+    else K2 = 0;
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_tn: N=%d > 288", N);
     HGV_REQUIRE(ldg < (1 << 27) && lda < (1 << 27), HGV_EUNSUPPORTED, "gemm_tn: leading dimension too large");
-    HGV_REQUIRE(ws_bytes >= hgv_gemm_tn_ws(M, N, K) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
-    const TdPlan p = td_plan(M, N, K);
+    HGV_REQUIRE(ws_bytes >= tn_ws_bytes(M, N, K, K2) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
+    const TdPlan p = td_plan(M, N, K, K2);
     const size_t sets = p.sets > 0 ? p.sets : 1;
     float* partial = (float*)ws;
     float* bias_partial = (float*)((char*)ws + hgv_align256(sets * p.tile_elems * 4));
@@ -922,6 +935,7 @@ extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, i
     if (p.sets > 0) {
         TdArgs g{};
         g.G = G; g.ldg = ldg; g.N = N; g.A = A; g.lda = lda; g.K = K; g.Mf = Mf;
+        g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.kblk1 = p.kblk1;
         g.rows_per_slice = p.rows_per_slice; g.sets = p.sets; g.ngrp = p.ngrp; g.kblk = p.kblk;
         g.partial = partial; g.bias_partial = gbias ? bias_partial : nullptr;
         int rc = HGV_EUNSUPPORTED;
@@ -946,8 +960,32 @@ extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, i
     r.wn = p.wn; r.nb = p.nb; r.wk = p.wk; r.ngrp = p.ngrp; r.kblk = p.kblk;
     r.g_last = G + Mf * ldg; r.a_last = A + Mf * lda; r.ldg = ldg; r.lda = lda; r.n_last = (int)(M - Mf);
     r.N = N; r.K = K; r.GW = GW; r.ldgw = ldgw; r.gbias = gbias; r.accumulate = accumulate;
+    r.a_last2 = A2 ? A2 + Mf * lda2 : nullptr; r.lda2 = lda2; r.K2 = K2; r.kblk1 = p.kblk1; r.GW2 = GW2; r.ldgw2 = ldgw2;
     const int64_t elems = p.tile_elems + (gbias ? p.bias_elems : 0);
     hipLaunchKernelGGL(k_reduce_tn, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn");
     return HGV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) { return tn_ws_bytes(M, N, K, 0); }
+extern "C" size_t hgv_gemm_tn2_ws(int64_t M, int N, int K1, int K2) { return tn_ws_bytes(M, N, K1, K2); }
+
+// GW[N,K] (row-major, leading dimension ldgw >= K) (+)= G[M,N]^T A[M,K];  gbias[N] (+)= column sums of G (nullable).
+// accumulate != 0 adds to GW / gbias (gradient accumulation into an existing .grad buffer) instead of overwriting.
+// G and A are row-major with leading dimensions >= their widths (any 4-byte aligned pointers).
+extern "C" int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M,
+                           float* GW, int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes,
+                           hipStream_t stream) {
+    return gemm_tn_impl(G, ldg, N, A, lda, K, GW, ldgw, nullptr, 0, 0, nullptr, 0, M, gbias, accumulate, ws, ws_bytes, stream);
+}
+
+// Two weight gradients that share G in one pass: GW1[N,K1] (+)= G^T A1 and GW2[N,K2] (+)= G^T A2 (the two halves of
+// a K-concatenated projection; GW1 / GW2 may be column blocks of one matrix); gbias as in hgv_gemm_tn.
+extern "C" int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                            const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
+                            int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HGV_REQUIRE(A2 && GW2, HGV_EINVAL, "gemm_tn2: null second source");
+    return gemm_tn_impl(G, ldg, N, A1, lda1, K1, GW1, ldgw1, A2, lda2, K2, GW2, ldgw2, M, gbias, accumulate, ws, ws_bytes, stream);
 }

@@ -301,6 +301,28 @@ def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out
     return gw, gb
 
 
+def _check_gw(gw, n, k):
+    if tuple(gw.shape) != (n, k) or gw.stride(1) != 1 or gw.stride(0) < k:
+        raise _lib.HgvError(f"weight-gradient output of shape {tuple(gw.shape)} / strides {gw.stride()} for a {n}x{k} product")
+
+
+def _gemm_tn2(g, xa, xb, want_bias: bool, out_a=None, out_b=None, bias_out=None, accumulate: bool = False):
+    """(g^T @ xa [N, Ka], g^T @ xb [N, Kb], column sums of g or None) in one pass over g; see :func:`_gemm_tn`."""
+    m, n, ka, kb = g.size(0), g.size(1), xa.size(1), xb.size(1)
+    if accumulate and (out_a is None or out_b is None or (want_bias and bias_out is None)):
+        raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
+    ga = torch.empty(n, ka, dtype=torch.float32, device=g.device) if out_a is None else out_a
+    gb_ = torch.empty(n, kb, dtype=torch.float32, device=g.device) if out_b is None else out_b
+    _check_gw(ga, n, ka)
+    _check_gw(gb_, n, kb)
+    gbias = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
+    ws = _workspace(_lib.load().hgv_gemm_tn2_ws(m, n, ka, kb), g.device, "gemm_tn")
+    _lib.call("hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
+              xb.data_ptr(), ld_of(xb), kb, gb_.data_ptr(), gb_.stride(0), m, _lib.ptr(gbias), 1 if accumulate else 0,
+              ws.data_ptr(), ws.numel(), _lib.stream())
+    return ga, gb_, gbias
+
+
 def _weight_grad(g, x, w, bias=None, want_bias: bool = False):
     """Weight (and bias) gradient of y = x @ w^T + bias: (gw, gb) for autograd, with None in place of a
     gradient that was added straight into the parameter's ``.grad`` buffer."""
@@ -311,6 +333,17 @@ def _weight_grad(g, x, w, bias=None, want_bias: bool = False):
         return None, None
     gw, gb = _gemm_tn(g, x, want_bias)
     return gw, gb
+
+
+def _weight_grad2(g, xa, wa, xb, wb, bias=None, want_bias: bool = False):
+    """Weight gradients of y = xa @ wa^T + xb @ wb^T + bias in one pass over g: (gwa, gwb, gb) for autograd,
+    None where the gradient was added straight into the parameter's ``.grad`` buffer."""
+    abuf, bbuf_w = _grad_buffer(wa), _grad_buffer(wb)
+    bbuf = _grad_buffer(bias) if want_bias else None
+    if abuf is not None and bbuf_w is not None and (not want_bias or bbuf is not None):
+        _gemm_tn2(g, xa, xb, want_bias, abuf, bbuf_w, bbuf, accumulate=True)
+        return None, None, None
+    return _gemm_tn2(g, xa, xb, want_bias)
 
 
 class _DualLinear(torch.autograd.Function):
@@ -342,15 +375,17 @@ class _DualLinear(torch.autograd.Function):
         want_bias = ctx.has_bias and need[4]
         if need[0]:
             gxa = _gemm_nt(g, ctx.pat, None, None, wa.size(1))
-        if need[1]:
-            gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
-        elif want_bias:
-            _, gb = _gemm_tn(g, xa, True)
-        if ctx.has_b:
-            if need[2]:
-                gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
-            if need[3]:
+        if ctx.has_b and need[1] and need[3]:
+            gwa, gwb, gb = _weight_grad2(g, xa, wa, xb, wb, bias, want_bias)
+        else:
+            if need[1]:
+                gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
+            elif want_bias:
+                _, gb = _gemm_tn(g, xa, True)
+            if ctx.has_b and need[3]:
                 gwb, _ = _weight_grad(g, xb, wb)
+        if ctx.has_b and need[2]:
+            gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
         return gxa, gwa, gxb, gwb, gb
 
 
@@ -394,12 +429,10 @@ class _ConcatLinear(torch.autograd.Function):
             wbuf = _grad_buffer(w) if need[2] else None
             bbuf = _grad_buffer(bias) if want_bias else None
             if wbuf is not None and (not want_bias or bbuf is not None):     # add both halves into w.grad
-                _gemm_tn(g, xa, want_bias, wbuf[:, :ka], bbuf, accumulate=True)
-                _gemm_tn(g, xb, False, wbuf[:, ka:], None, accumulate=True)
+                _gemm_tn2(g, xa, xb, want_bias, wbuf[:, :ka], wbuf[:, ka:], bbuf, accumulate=True)
             else:
                 gw = torch.empty_like(w, memory_format=torch.contiguous_format)
-                _, gb = _gemm_tn(g, xa, want_bias, gw[:, :ka])
-                _gemm_tn(g, xb, False, gw[:, ka:])
+                _, _, gb = _gemm_tn2(g, xa, xb, want_bias, gw[:, :ka], gw[:, ka:])
                 if not need[2]:
                     gw = None
         return gxa, gxb, gw, gb
@@ -473,8 +506,11 @@ class _SageConv(torch.autograd.Function):
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
-            gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
-            gwr, _ = _weight_grad(g, x, wr)
+            if need[1] and need[3]:
+                gwl, gwr, gb = _weight_grad2(g, agg, wl, x, wr, bl, want_bias)
+            else:
+                gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
+                gwr, _ = _weight_grad(g, x, wr)
             if need[0] and ctx.pt is not None:
                 gt = new_padded(n, n_out, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)

@@ -198,6 +198,13 @@ int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W1, int64_t 
 size_t hgv_gemm_tn_ws(int64_t M, int N, int K);
 int hgv_gemm_tn(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, int64_t M, float* GW,
                 int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* Two weight gradients that share G in one pass over it (the halves of a K-concatenated projection:
+ * SAGEConv's lin_l / lin_r, gvae/gvae_skipcon.py:61, and a decoder level fed by [h | skip], :92-100):
+ * GW1[N,K1] (+)= G^T A1, GW2[N,K2] (+)= G^T A2; GW1 / GW2 may be column blocks of one matrix. */
+size_t hgv_gemm_tn2_ws(int64_t M, int N, int K1, int K2);
+int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                 const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
+                 void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 /* ---- the same projections on the bf16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
