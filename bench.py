@@ -197,7 +197,7 @@ def main():
     tot_graphs, tot_edges, tot_nodes = stats[1].item(), stats[2].item(), stats[3].item()
 
     if rank == 0:
-        # roofline of the dominant kernel k_aggregate<4,false> (unweighted aggregation, every width it ran at):
+        # roofline of the dominant kernel k_aggregate<4,false,*> (unweighted aggregation, every width it ran at):
         # sum of algorithmic bytes / sum of launch durations, so that avg_launch_us is directly comparable with
         # the rocprofv3 --kernel-trace --stats average for that kernel name
         recs = probe.durations_ms()
@@ -210,7 +210,7 @@ def main():
             tot_b = sum(agg_bytes(n, f, e) for (n, f, e, ms) in dom)
             achieved = tot_b / (tot_ms * 1e-3) / 1e9
             at_h = [ms for (n, f, e, ms) in dom if f == h]
-            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false>", "achieved": round(achieved, 1),
+            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false,*>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": measured_traffic(args.workload, h),
                     "avg_launch_us": round(tot_ms / len(dom) * 1e3, 2), "launches": len(dom),
@@ -219,7 +219,7 @@ def main():
                     "at_hidden_width": {"F": h, "avg_launch_us": round(sum(at_h) / len(at_h) * 1e3, 2) if at_h else None,
                                         "algorithmic_bytes": agg_bytes(n_nodes, h, n_edges),
                                         "traffic_note": "traffic is the PMC-measured HBM bytes of one launch at this width"},
-                    "weighted_kernel": {"kernel": "k_aggregate<4,true>", "launches": len(wtd),
+                    "weighted_kernel": {"kernel": "k_aggregate<4,true,*>", "launches": len(wtd),
                                         "avg_launch_us": round(sum(ms for (*_, ms) in wtd) / len(wtd) * 1e3, 2) if wtd else None,
                                         "achieved": round(sum(agg_bytes(n, f, e) + 4 * e for (n, f, e, ms) in wtd)
                                                           / (sum(ms for (*_, ms) in wtd) * 1e-3) / 1e9, 1) if wtd else None}}
