@@ -66,11 +66,34 @@ struct AggArgs {
     int64_t ldo;
 };
 
+// NB neighbour rows (x CPL chunks) of one segment position in flight per lane; adds stay in segment order
+template <int VEC, bool WEIGHTED, int CPL, int NB>
+__device__ __forceinline__ void agg_batch(typename VecT<VEC>::T (&acc)[CPL], const AggArgs& a, const int (&coff)[CPL],
+                                          int my_col, float my_w, int j, int L) {
+    using V = typename VecT<VEC>::T;
+    V v[NB][CPL];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float* r = a.x + (int64_t)__shfl(my_col, j + u, L) * a.ldx;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v[u][q] = *reinterpret_cast<const V*>(r + coff[q]);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const float w = WEIGHTED ? __shfl(my_w, j + u, L) : 1.f;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+            if (WEIGHTED) vmad(acc[q], w, v[u][q]);
+            else vadd(acc[q], v[u][q]);
+        }
+    }
+}
+
 // CPL = feature chunks per lane: lane l of a group owns chunks l, l + L, ..., l + (CPL-1) L of a pass.
 // Several chunks per lane mean fewer lanes per row (more rows per wave, fewer idle lanes when the
 // chunk count is not a power of two: 35 chunks = 16 lanes x 3 instead of 64 x 1) and one column
 // index / address computation for CPL row loads.
-template <int VEC, bool WEIGHTED, int CPL>
+template <int VEC, bool WEIGHTED, int CPL, int NB>
 __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
     using V = typename VecT<VEC>::T;
     const int lane = threadIdx.x & 63;
@@ -110,40 +133,10 @@ __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
             }
             const int cnt = min(L, end - base);
             int j = 0;
-            // four neighbour rows (x CPL chunks) in flight per lane; adds stay in segment order
-            for (; j + 4 <= cnt; j += 4) {
-                const float* r0 = a.x + (int64_t)__shfl(my_col, j, L) * a.ldx;
-                const float* r1 = a.x + (int64_t)__shfl(my_col, j + 1, L) * a.ldx;
-                const float* r2 = a.x + (int64_t)__shfl(my_col, j + 2, L) * a.ldx;
-                const float* r3 = a.x + (int64_t)__shfl(my_col, j + 3, L) * a.ldx;
-                V v0[CPL], v1[CPL], v2[CPL], v3[CPL];
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    v0[q] = *reinterpret_cast<const V*>(r0 + coff[q]);
-                    v1[q] = *reinterpret_cast<const V*>(r1 + coff[q]);
-                    v2[q] = *reinterpret_cast<const V*>(r2 + coff[q]);
-                    v3[q] = *reinterpret_cast<const V*>(r3 + coff[q]);
-                }
-                if (WEIGHTED) {
-                    const float w0 = __shfl(my_w, j, L), w1 = __shfl(my_w, j + 1, L);
-                    const float w2 = __shfl(my_w, j + 2, L), w3 = __shfl(my_w, j + 3, L);
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) { vmad(acc[q], w0, v0[q]); vmad(acc[q], w1, v1[q]); vmad(acc[q], w2, v2[q]); vmad(acc[q], w3, v3[q]); }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) { vadd(acc[q], v0[q]); vadd(acc[q], v1[q]); vadd(acc[q], v2[q]); vadd(acc[q], v3[q]); }
-                }
-            }
-            for (; j < cnt; ++j) {
-                const float* r = a.x + (int64_t)__shfl(my_col, j, L) * a.ldx;
-                const float wj = WEIGHTED ? __shfl(my_w, j, L) : 1.f;
-#pragma unroll
-                for (int q = 0; q < CPL; ++q) {
-                    const V v = *reinterpret_cast<const V*>(r + coff[q]);
-                    if (WEIGHTED) vmad(acc[q], wj, v);
-                    else vadd(acc[q], v);
-                }
-            }
+            for (; j + NB <= cnt; j += NB) agg_batch<VEC, WEIGHTED, CPL, NB>(acc, a, coff, my_col, my_w, j, L);
+            if (NB > 2)
+                for (; j + 2 <= cnt; j += 2) agg_batch<VEC, WEIGHTED, CPL, 2>(acc, a, coff, my_col, my_w, j, L);
+            for (; j < cnt; ++j) agg_batch<VEC, WEIGHTED, CPL, 1>(acc, a, coff, my_col, my_w, j, L);
         }
         const int d = end - start;
 #pragma unroll
@@ -196,12 +189,13 @@ int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
     if (nblocks == 0) return HGV_OK;
     HGV_REQUIRE(nblocks < ((int64_t)1 << 31), HGV_EUNSUPPORTED, "aggregate: too many rows");
     dim3 g((unsigned)nblocks), b(64 * wpb);
+    // neighbour rows in flight per lane: 4 x (1-2 chunks) or 2 x (3-4 chunks) - measured: occupancy beats deeper batches
 #define HGV_AGG_CPL(V, W)                                                                          \
     switch (cpl) {                                                                                 \
-        case 1: hipLaunchKernelGGL((k_aggregate<V, W, 1>), g, b, 0, st, a); break;                 \
-        case 2: hipLaunchKernelGGL((k_aggregate<V, W, 2>), g, b, 0, st, a); break;                 \
-        case 3: hipLaunchKernelGGL((k_aggregate<V, W, 3>), g, b, 0, st, a); break;                 \
-        default: hipLaunchKernelGGL((k_aggregate<V, W, 4>), g, b, 0, st, a); break;                \
+        case 1: hipLaunchKernelGGL((k_aggregate<V, W, 1, 4>), g, b, 0, st, a); break;              \
+        case 2: hipLaunchKernelGGL((k_aggregate<V, W, 2, 4>), g, b, 0, st, a); break;              \
+        case 3: hipLaunchKernelGGL((k_aggregate<V, W, 3, 2>), g, b, 0, st, a); break;              \
+        default: hipLaunchKernelGGL((k_aggregate<V, W, 4, 2>), g, b, 0, st, a); break;             \
     }
 #define HGV_AGG_LAUNCH(V)                                                                          \
     if (weighted) { HGV_AGG_CPL(V, true) } else { HGV_AGG_CPL(V, false) }
