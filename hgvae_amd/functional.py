@@ -523,6 +523,34 @@ class _SageConv(torch.autograd.Function):
         return gx, gwl, gb, gwr, None, None
 
 
+class _Fork(torch.autograd.Function):
+    """Two handles on one tensor for two consumers.  Autograd alone would add the two incoming
+    gradients into a dense [N, F] tensor, which every kernel downstream then has to re-pad (a copy)
+    or read with unaligned rows; here the sum is written in the padded layout directly."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        if ga.dim() != 2 or not ga.is_cuda:
+            return ga + gb
+        out = new_padded(ga.size(0), ga.size(1), ga.device)
+        torch.add(ga, gb, out=out)
+        return out
+
+
+def fork(x: torch.Tensor):
+    """(x, x) for a tensor with two consumers; see :class:`_Fork`."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return _Fork.apply(x)
+
+
 def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True):
     if x.size(0) != graph.num_nodes:
         raise _lib.HgvError(f"x has {x.size(0)} rows but the graph has {graph.num_nodes} nodes")

@@ -114,8 +114,8 @@ class SkipconVAE(_VAEBase):
         if memo is not None and memo[0] is x and memo[1] is g and memo[2] == key:
             self._conv1_memo = None
             return memo[3]
-        y = conv(x, g)
-        self._conv1_memo = (x, g, key, y)
+        y, y_again = Fn.fork(conv(x, g))
+        self._conv1_memo = (x, g, key, y_again)
         return y
 
     def _make_level2(self, h, p):
@@ -127,11 +127,12 @@ class SkipconVAE(_VAEBase):
     def encode(self, x, edge_index):
         g = graph_of(edge_index, x.size(0))
         x = padded_input(x)
-        x1 = self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True)
-        x2 = self._level2(x1, g)
+        # x1 / x2 feed the next level and, as skips, the decoder: explicit forks keep their summed gradients padded
+        x1, skip1 = Fn.fork(self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True))
+        x2, skip2 = Fn.fork(self._level2(x1, g))
         x3 = self._sage_level(self.encoder3, x2, g)
         mean, log_std = split_head(self.encoder3[3](x3, g), self.out_channels)
-        return x1, x2, mean, log_std
+        return skip1, skip2, mean, log_std
 
     def decode(self, z, skip1, skip2):
         d1, d2, d3 = self.decoder1, self.decoder2, self.decoder3
