@@ -443,6 +443,258 @@ int launch_nt16_both(const Nt16Args& a, int nt0, int nt1, size_t lds, hipStream_
 
 }  // namespace
 
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores:  GW[n][k] = sum_m G[m][n] A[m][k]
+// ------------------------------------------------------------------------------------------
+// Both operands are reduced over their ROW index, so an MFMA lane needs 8 consecutive rows of one
+// column, while coalesced loads deliver consecutive columns of one row.  A workgroup therefore stages
+// 32-row tiles (144 columns of G, 144 columns of A) in LDS row-major as three bf16 pieces and reads
+// the operands back with the transposing ds_read_b64_tr_b16.  LDS image of a piece: 18 panels of 16
+// columns, a panel = 32 row slots of 32 bytes (+32 bytes of padding so that the four panels a 16-lane
+// group writes fall into different banks); row r sits in slot r with bits 2 and 3 swapped, which makes
+// the two 4-row blocks a 32-lane half reads (rows 8kq.. and 8(kq+1)..) cover all 64 banks once.
+// Two buffers, one barrier per step: while the matrix cores work on one buffer every wave splits its
+// share (3 float4 per thread) of the next step into the other.  Wave (wn = id % 3, wk = id / 3) owns
+// n tiles 3wn..3wn+2 and k tiles {0,1,2}, {3,4}, {5,6}, {7,8} for wk = 0..3, which gives the four
+// SIMDs (waves id, id+4, id+8 share one) 21, 21, 21 and 18 tiles; waves with wk == 1 also form the
+// column sums of G (products with a tile of ones).  A workgroup covers one (n group, k group) of 144 x
+// 144 outputs over a slice of the rows and writes its 81 accumulator tiles as a partial set;
+// k_reduce_tn16 adds the sets in fp64 in a fixed order, adds the rows the 32-row steps did not cover
+// and writes (or accumulates into) the final matrices.
+constexpr int T16_ROWS = 32;
+constexpr int T16_PANEL = 1024 + 32;
+constexpr int T16_PIECE = 18 * T16_PANEL;
+constexpr int T16_BUF = 3 * T16_PIECE;
+constexpr int T16_THREADS = 768;
+constexpr int T16_SET_FLOATS = 81 * 256;
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct Tn16Args {
+    const float* G; int64_t ldg; int N;
+    const float* A[2]; int64_t lda[2]; int K[2];
+    int kg0;                   // k groups (144 columns each) of the first source
+    int ngrps, kgrps;          // groups over N and over both sources' K
+    int64_t steps;             // 32-row steps in total
+    int sets;                  // row slices per group pair
+    float* partial;            // [ngrp][kgrp][set][81][4][64]
+    float* bias_partial;       // [ngrp][set][9][4][64], written by the workgroups of k group 0 (null: no bias)
+};
+
+__device__ __forceinline__ int t16_slot(int r) { return (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__device__ __forceinline__ bf16x8 t16_read(const unsigned char* lds, int addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(lds + addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(lds + addr + 256));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+template <int KT>
+__device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds, const int wn, const int k0t, const bool bias) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int per = a.ngrps * a.kgrps;
+    const int grp = blockIdx.x % per, set = blockIdx.x / per;
+    const int ngrp = grp / a.kgrps, kgrp = grp - ngrp * a.kgrps;
+    const int second = kgrp >= a.kg0;
+    const int n_off = 144 * ngrp, k_off = 144 * (second ? kgrp - a.kg0 : kgrp);
+    const float* Ab = a.A[second]; const int64_t lda = a.lda[second];
+    const int n_w = min(144, a.N - n_off), k_w = min(144, a.K[second] - k_off);     // live widths of the two tiles
+    const int64_t s_lo = a.steps * set / a.sets, s_hi = a.steps * (set + 1) / a.sets;
+    // staging: float4 f = t + 768 u of the step's 64 x 36 (32 rows of G, then 32 rows of A).  Columns past
+    // the live width (rounded up to 4) re-read column 0: they only reach outputs that are never stored.
+    const float* src[3]; int64_t ld[3]; int waddr[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int f = t + T16_THREADS * u;
+        const int isa = f >= 1152, rem = isa ? f - 1152 : f;
+        const int row = rem / 36, c4 = rem - 36 * row, col = 4 * c4;
+        const int width = isa ? k_w : n_w;
+        const int ceff = col < (width + 3) / 4 * 4 ? col : 0;
+        ld[u] = isa ? lda : a.ldg;
+        src[u] = (isa ? Ab + k_off : a.G + n_off) + (int64_t)row * ld[u] + ceff;
+        waddr[u] = (isa * 9 + (col >> 4)) * T16_PANEL + t16_slot(row) * 32 + (col & 15) * 2;
+    }
+    f32x4 stage[3];
+    auto load_step = [&](int64_t s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) stage[u] = *reinterpret_cast<const f32x4*>(src[u] + s * T16_ROWS * ld[u]);
+    };
+    auto write_step = [&](int b) __attribute__((always_inline)) {
+        unsigned char* base = lds + b * T16_BUF;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            bf16x4 h, m, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { __bf16 hh, mm, ll; split3(stage[u][e], hh, mm, ll); h[e] = hh; m[e] = mm; l[e] = ll; }
+            *reinterpret_cast<bf16x4*>(base + waddr[u]) = h;
+            *reinterpret_cast<bf16x4*>(base + T16_PIECE + waddr[u]) = m;
+            *reinterpret_cast<bf16x4*>(base + 2 * T16_PIECE + waddr[u]) = l;
+        }
+    };
+    // operand read address inside a panel: lane 4q+p of the 16-lane group kq supplies row 8kq+q, columns 4p..4p+3
+    const int kq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int raddr = t16_slot(8 * kq + q) * 32 + p * 8;
+
+    f32x4 acc[3][KT], accb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+    if (s_lo < s_hi) {
+        load_step(s_lo);
+        write_step(0);
+        if (s_lo + 1 < s_hi) load_step(s_lo + 1);
+    }
+    __syncthreads();
+    for (int64_t s = s_lo; s < s_hi; ++s) {
+        const int b = (int)((s - s_lo) & 1);
+        const unsigned char* base = lds + b * T16_BUF;
+        bf16x8 g[3][3], x[KT][3];      // [tile][piece]
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i][pc] = t16_read(base, pc * T16_PIECE + (3 * wn + i) * T16_PANEL + raddr);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) x[j][pc] = t16_read(base, pc * T16_PIECE + (9 + k0t + j) * T16_PANEL + raddr);
+        }
+        // next step's tiles: split and store into the other buffer while the matrix cores work
+        if (s + 1 < s_hi) write_step(b ^ 1);
+        if (s + 2 < s_hi) load_step(s + 2);
+        // six piece products, small terms first: gl*xh, gh*xl, gm*xm, gh*xm, gm*xh, gh*xh
+#define HGV_TN_TERM(GP, XP)                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
+            _Pragma("unroll") for (int j = 0; j < KT; ++j)                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[i][GP], x[j][XP], acc[i][j], 0, 0, 0);
+        HGV_TN_TERM(2, 0) HGV_TN_TERM(0, 2) HGV_TN_TERM(1, 1) HGV_TN_TERM(0, 1) HGV_TN_TERM(1, 0) HGV_TN_TERM(0, 0)
+#undef HGV_TN_TERM
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int pc = 2; pc >= 0; --pc) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[i][pc], ones, accb[i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout: lane (j = lane & 15, q = lane >> 4), register r: n = 16 tn + 4 q + r, k = 16 tk + j
+    float* out = a.partial + ((int64_t)grp * a.sets + set) * T16_SET_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(((3 * wn + i) * 9 + k0t + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+    if (bias && a.bias_partial && kgrp == 0) {
+        float* bo = a.bias_partial + ((int64_t)ngrp * a.sets + set) * (9 * 256);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bo[((3 * wn + i) * 4 + r) * 64 + lane] = accb[i][r];
+    }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void k_gemm_tn16(const Tn16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wk = w / 3, wn = w - 3 * wk;
+    if (wk == 0) tn16_body<3>(a, lds_raw, wn, 0, false);
+    else tn16_body<2>(a, lds_raw, wn, 1 + 2 * wk, wk == 1);
+}
+
+struct Tr16Args {
+    Tn16Args t;
+    int64_t M;
+    float* GW[2]; int64_t ldgw[2];
+    float* gbias;
+    int accumulate;
+};
+
+// One workgroup: 64 consecutive floats of a partial set (coalesced) x 4 interleaved groups of sets.
+__global__ __launch_bounds__(256) void k_reduce_tn16(const Tr16Args r) {
+    __shared__ double sh[4][65];
+    const Tn16Args& a = r.t;
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int64_t tile_total = (int64_t)a.ngrps * a.kgrps * T16_SET_FLOATS;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
+    const bool is_bias = e >= tile_total;
+    const int64_t eb = e - tile_total;
+    const bool live = !is_bias || (r.gbias != nullptr && eb < (int64_t)a.ngrps * 9 * 256);
+    double s = 0.0;
+    int grp = 0, off = 0;
+    if (live) {
+        const float* src;
+        int64_t stride;
+        if (!is_bias) {
+            grp = (int)(e / T16_SET_FLOATS); off = (int)(e - (int64_t)grp * T16_SET_FLOATS);
+            src = a.partial + (int64_t)grp * a.sets * T16_SET_FLOATS + off; stride = T16_SET_FLOATS;
+        } else {
+            grp = (int)(eb / (9 * 256)); off = (int)(eb - (int64_t)grp * 9 * 256);
+            src = a.bias_partial + (int64_t)grp * a.sets * (9 * 256) + off; stride = 9 * 256;
+        }
+        double s0 = 0.0, s1 = 0.0;
+        int b = part;
+        for (; b + 4 < a.sets; b += 8) { s0 += (double)src[(int64_t)b * stride]; s1 += (double)src[(int64_t)(b + 4) * stride]; }
+        for (; b < a.sets; b += 4) s0 += (double)src[(int64_t)b * stride];
+        s = s0 + s1;
+    }
+    sh[part][el] = s;
+    __syncthreads();
+    if (part != 0 || !live) return;
+    double v = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
+    const int64_t covered = a.steps * T16_ROWS;
+    const int lane = off & 63, rr = (off >> 6) & 3, tile = off >> 8;
+    if (is_bias) {
+        if ((lane & 15) != 0) return;                            // every column of a ones product holds the same sum
+        const int n = 144 * grp + 16 * tile + 4 * (lane >> 4) + rr;
+        if (tile >= 9 || n >= a.N || n >= 144 * (grp + 1)) return;
+        for (int64_t m = covered; m < r.M; ++m) v += (double)a.G[m * a.ldg + n];
+        r.gbias[n] = r.accumulate ? r.gbias[n] + (float)v : (float)v;
+    } else {
+        const int ngrp = grp / a.kgrps, kgrp = grp - ngrp * a.kgrps;
+        const int second = kgrp >= a.kg0;
+        const int tn = tile / 9, tk = tile - 9 * tn;
+        const int nl = 16 * tn + 4 * (lane >> 4) + rr, kl = 16 * tk + (lane & 15);
+        const int n = 144 * ngrp + nl, k = 144 * (second ? kgrp - a.kg0 : kgrp) + kl;
+        if (n >= a.N || k >= a.K[second]) return;
+        const float* Ab = a.A[second]; const int64_t lda = a.lda[second];
+        for (int64_t m = covered; m < r.M; ++m) v += (double)a.G[m * a.ldg + n] * (double)Ab[m * lda + k];
+        float* dst = r.GW[second] + (int64_t)n * r.ldgw[second] + k;
+        *dst = r.accumulate ? *dst + (float)v : (float)v;
+    }
+}
+
+struct Tn16Plan { int ngrps, kg0, kgrps, sets; int64_t steps; bool ok; };
+
+// Shapes worth the staging: rows for at least a few steps per workgroup and tiles that are mostly live.
+Tn16Plan tn16_plan(int64_t M, int N, int K1, int K2) {
+    Tn16Plan p{};
+    p.ngrps = (int)hgv_cdiv(N, 144);
+    p.kg0 = (int)hgv_cdiv(K1, 144);
+    p.kgrps = p.kg0 + (K2 > 0 ? (int)hgv_cdiv(K2, 144) : 0);
+    p.steps = (M - 1) / T16_ROWS;                      // the last 1..32 rows are added by the reduction
+    const int per = p.ngrps * p.kgrps;
+    int64_t sets = cu_count16() / per;
+    if (sets < 1) sets = 1;
+    if (sets > p.steps / 4) sets = p.steps / 4;
+    p.sets = (int)sets;
+    const double live = (double)N * (K1 + K2) / ((double)per * 144 * 144);
+    p.ok = N > 0 && K1 > 0 && K2 >= 0 && p.sets >= 1 && live >= 0.6 && p.ngrps <= 2;
+    return p;
+}
+
+}  // namespace
+
 // 1 when hgv_gemm_nt16 can run this shape (the split weight image, whole or in two parts along N, fits in LDS)
 extern "C" int hgv_gemm_nt16_supported(int N, int K1, int K2) {
     Geo16 g;
@@ -507,5 +759,47 @@ extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float*
     }
     if (rc != HGV_OK) return rc;
     HGV_CHECK_LAUNCH("gemm_nt16");
+    return HGV_OK;
+}
+
+// ---- weight gradients on the bf16 matrix cores (same contract as hgv_gemm_tn / hgv_gemm_tn2) --------------------
+// 1 when hgv_gemm_tn16 runs this shape (enough rows, tiles mostly live); buffers must be 16-byte aligned with
+// leading dimensions that are multiples of 4.
+extern "C" int hgv_gemm_tn16_supported(int64_t M, int N, int K1, int K2) { return tn16_plan(M, N, K1, K2).ok ? 1 : 0; }
+
+extern "C" size_t hgv_gemm_tn16_ws(int64_t M, int N, int K1, int K2) {
+    const Tn16Plan p = tn16_plan(M, N, K1, K2);
+    if (!p.ok) return 256;
+    return hgv_align256((size_t)p.ngrps * p.kgrps * p.sets * T16_SET_FLOATS * 4) + hgv_align256((size_t)p.ngrps * p.sets * 9 * 256 * 4);
+}
+
+// GW1[N,K1] (+)= G^T A1, GW2[N,K2] (+)= G^T A2 (A2 / GW2 null for a single product), gbias[N] (+)= column sums of G.
+extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                             const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
+                             int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!A2) K2 = 0;
+    HGV_REQUIRE(M > 0 && N > 0 && K1 > 0 && (A2 ? K2 > 0 && GW2 : true), HGV_EINVAL, "gemm_tn16: bad sizes");
+    const Tn16Plan p = tn16_plan(M, N, K1, K2);
+    HGV_REQUIRE(p.ok, HGV_EUNSUPPORTED, "gemm_tn16: shape %lld x %d x (%d + %d) is not supported", (long long)M, N, K1, K2);
+    HGV_REQUIRE(G && A1 && GW1 && ws && hgv_aligned(G, 16) && hgv_aligned(A1, 16) && ldg % 4 == 0 && lda1 % 4 == 0 &&
+                ldg >= N && lda1 >= K1 && ldgw1 >= K1, HGV_EINVAL, "gemm_tn16: null / misaligned buffer or bad leading dimension");
+    if (A2) HGV_REQUIRE(hgv_aligned(A2, 16) && lda2 % 4 == 0 && lda2 >= K2 && ldgw2 >= K2, HGV_EINVAL,
+                        "gemm_tn16: misaligned second source or bad leading dimension");
+    HGV_REQUIRE(ws_bytes >= hgv_gemm_tn16_ws(M, N, K1, K2) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn16: workspace too small or misaligned");
+    Tr16Args r{};
+    Tn16Args& a = r.t;
+    a.G = G; a.ldg = ldg; a.N = N;
+    a.A[0] = A1; a.lda[0] = lda1; a.K[0] = K1; a.A[1] = A2 ? A2 : A1; a.lda[1] = A2 ? lda2 : lda1; a.K[1] = K2;
+    a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.steps = p.steps; a.sets = p.sets;
+    a.partial = (float*)ws;
+    a.bias_partial = gbias ? (float*)((char*)ws + hgv_align256((size_t)p.ngrps * p.kgrps * p.sets * T16_SET_FLOATS * 4)) : nullptr;
+    const size_t lds = 2 * T16_BUF;
+    const int rc = raise_lds16(k_gemm_tn16);
+    if (rc != HGV_OK) return rc;
+    hipLaunchKernelGGL(k_gemm_tn16, dim3((unsigned)(p.ngrps * p.kgrps * p.sets)), dim3(T16_THREADS), lds, stream, a);
+    r.M = M; r.GW[0] = GW1; r.ldgw[0] = ldgw1; r.GW[1] = GW2; r.ldgw[1] = ldgw2; r.gbias = gbias; r.accumulate = accumulate;
+    const int64_t elems = (int64_t)p.ngrps * p.kgrps * T16_SET_FLOATS + (gbias ? (int64_t)p.ngrps * 9 * 256 : 0);
+    hipLaunchKernelGGL(k_reduce_tn16, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
+    HGV_CHECK_LAUNCH("gemm_tn16");
     return HGV_OK;
 }

@@ -283,6 +283,14 @@ def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return g
 
 
+def _tn16_ok(m, n, k1, k2, *mats) -> bool:
+    """Weight gradients run on the bf16 matrix cores (split operands, fp32-accurate) when the projection
+    arithmetic is "bf16x6", the shape is one the kernel covers and the operands are 16-byte aligned."""
+    if _projection != "bf16x6" or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
+        return False
+    return all(t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 for t in mats)
+
+
 def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out: Optional[torch.Tensor] = None,
              accumulate: bool = False):
     """(g^T @ x  [N, K],  column sums of g or None); g, x in the padded layout.  ``out`` may be a
@@ -295,6 +303,11 @@ def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out
     if accumulate and (out is None or (want_bias and bias_out is None)):
         raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
     gb = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
+    if _tn16_ok(m, n, k, 0, g, x):
+        ws = _workspace(_lib.load().hgv_gemm_tn16_ws(m, n, k, 0), g.device, "gemm_tn")
+        _lib.call("hgv_gemm_tn16", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, gw.data_ptr(), gw.stride(0),
+                  None, 0, 0, None, 0, m, _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        return gw, gb
     ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
     _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), gw.stride(0),
               _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
@@ -316,8 +329,9 @@ def _gemm_tn2(g, xa, xb, want_bias: bool, out_a=None, out_b=None, bias_out=None,
     _check_gw(ga, n, ka)
     _check_gw(gb_, n, kb)
     gbias = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
-    ws = _workspace(_lib.load().hgv_gemm_tn2_ws(m, n, ka, kb), g.device, "gemm_tn")
-    _lib.call("hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
+    tn16 = _tn16_ok(m, n, ka, kb, g, xa, xb)
+    ws = _workspace((_lib.load().hgv_gemm_tn16_ws if tn16 else _lib.load().hgv_gemm_tn2_ws)(m, n, ka, kb), g.device, "gemm_tn")
+    _lib.call("hgv_gemm_tn16" if tn16 else "hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
               xb.data_ptr(), ld_of(xb), kb, gb_.data_ptr(), gb_.stride(0), m, _lib.ptr(gbias), 1 if accumulate else 0,
               ws.data_ptr(), ws.numel(), _lib.stream())
     return ga, gb_, gbias

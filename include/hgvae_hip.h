@@ -224,6 +224,16 @@ int hgv_pack16_weights_multi(int njobs, const float* const* W1, const int64_t* s
 int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                   const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
 
+/* Weight gradients of the same projections on the bf16 matrix cores (three-piece split of both operands, six piece
+ * products, fp32 accumulation per row slice, fp64 across slices): contract of hgv_gemm_tn2 with A2 / GW2 nullable, plus
+ * 16-byte aligned G / A1 / A2 with leading dimensions that are multiples of 4.  hgv_gemm_tn16_supported: 1 for shapes
+ * it runs (N <= 288, enough rows, 144 x 144 tiles mostly live); otherwise use hgv_gemm_tn / hgv_gemm_tn2. */
+int hgv_gemm_tn16_supported(int64_t M, int N, int K1, int K2);
+size_t hgv_gemm_tn16_ws(int64_t M, int N, int K1, int K2);
+int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                  const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
+                  void* ws, size_t ws_bytes, hgv_stream_t stream);
+
 /* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
  *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------
  * hgv_adam_step: torch's Adam arithmetic (bias-corrected, eps added after the sqrt(v)/sqrt(1-b2^t) division,

@@ -500,26 +500,31 @@ def test_projection_kernels_at_benchmark_rows(shape, kind):
     gx = Fn._gemm_nt(g, img_t, None, None, k1)                            # grad-input product
     refx = g.double() @ w[:, :k1].double()
     assert float((gx.double() - refx).abs().max()) <= 2e-6 * float(refx.abs().max()) * n ** 0.5
-    gw, gb = Fn._gemm_tn(g, xa, True)
-    refw, refb = g.double().t() @ xa.double(), g.double().sum(0)
-    # M-long fp32 accumulations in slices, fp64 across slices: error ~ 1e-7 * sqrt(rows per slice) * |terms|
-    assert float((gw.double() - refw).abs().max()) <= 2e-6 * float(refw.abs().max()) + 1e-7 * m ** 0.5 * 4
-    assert float((gb.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
-    if k2:
-        # both halves in one pass over g, written as column blocks of one matrix, then accumulated once more
-        both = torch.zeros(n, k1 + k2, device=dev())
-        bsum = torch.zeros(n, device=dev())
-        Fn._gemm_tn2(g, xa, xb, True, both[:, :k1], both[:, k1:], bsum)
-        refw2 = g.double().t() @ torch.cat([xa, xb], 1).double()
-        tol = 2e-6 * float(refw2.abs().max()) + 1e-7 * m ** 0.5 * 4
-        assert float((both.double() - refw2).abs().max()) <= tol
-        assert float((bsum.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
-        Fn._gemm_tn2(g, xa, xb, True, both[:, :k1], both[:, k1:], bsum, accumulate=True)
-        assert float((both.double() - 2 * refw2).abs().max()) <= 2 * tol
+    Fn.set_projection(kind)              # the weight-gradient kernels follow the projection arithmetic as well
+    try:
+        gw, gb = Fn._gemm_tn(g, xa, True)
+        refw, refb = g.double().t() @ xa.double(), g.double().sum(0)
+        # M-long fp32 accumulations in slices, fp64 across slices: error ~ 1e-7 * sqrt(rows per slice) * |terms|
+        assert float((gw.double() - refw).abs().max()) <= 2e-6 * float(refw.abs().max()) + 1e-7 * m ** 0.5 * 4
+        assert float((gb.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
+        if k2:
+            # both halves in one pass over g, written as column blocks of one matrix, then accumulated once more
+            both = torch.zeros(n, k1 + k2, device=dev())
+            bsum = torch.zeros(n, device=dev())
+            Fn._gemm_tn2(g, xa, xb, True, both[:, :k1], both[:, k1:], bsum)
+            refw2 = g.double().t() @ torch.cat([xa, xb], 1).double()
+            tol = 2e-6 * float(refw2.abs().max()) + 1e-7 * m ** 0.5 * 4
+            assert float((both.double() - refw2).abs().max()) <= tol
+            assert float((bsum.double() - refb).abs().max()) <= 2e-6 * float(refb.abs().max()) + 1e-7 * m ** 0.5 * 4
+            Fn._gemm_tn2(g, xa, xb, True, both[:, :k1], both[:, k1:], bsum, accumulate=True)
+            assert float((both.double() - 2 * refw2).abs().max()) <= 2 * tol
+    finally:
+        Fn.set_projection("bf16x6")
 
 
 @pytest.mark.parametrize("m,n,k1,k2", [(1, 5, 3, 2), (4, 16, 16, 16), (5, 17, 33, 7), (37, 138, 138, 28), (1000, 56, 138, 138),
-                                       (4099, 138, 105, 105), (3001, 276, 138, 6), (2500, 1, 276, 138)])
+                                       (4099, 138, 105, 105), (3001, 276, 138, 6), (2500, 1, 276, 138), (9000, 256, 256, 256),
+                                       (6000, 138, 276, 138), (5000, 150, 144, 145)])
 def test_weight_gradient_pair_small_shapes(m, n, k1, k2):
     """hgv_gemm_tn2 on ragged shapes (rows not a multiple of 4, widths off the tile sizes, different K per source)."""
     from hgvae_amd import functional as Fn
