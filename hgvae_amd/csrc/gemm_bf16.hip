@@ -461,8 +461,8 @@ namespace {
 // SIMDs (waves id, id+4, id+8 share one) 21, 21, 21 and 18 tiles; waves with wk == 1 also form the
 // column sums of G (products with a tile of ones).  A workgroup covers one (n group, k group) of 144 x
 // 144 outputs over a slice of the rows and writes its 81 accumulator tiles as a partial set;
-// k_reduce_tn16 adds the sets in fp64 in a fixed order, adds the rows the 32-row steps did not cover
-// and writes (or accumulates into) the final matrices.
+// k_reduce_tn16 adds the sets in fp64 in a fixed order and writes (or accumulates into) the final
+// matrices.
 constexpr int T16_ROWS = 32;
 constexpr int T16_PANEL = 1024 + 32;
 constexpr int T16_PIECE = 18 * T16_PANEL;
@@ -478,7 +478,8 @@ struct Tn16Args {
     const float* A[2]; int64_t lda[2]; int K[2];
     int kg0;                   // k groups (144 columns each) of the first source
     int ngrps, kgrps;          // groups over N and over both sources' K
-    int64_t steps;             // 32-row steps in total
+    int64_t M;
+    int64_t steps;             // 32-row steps in total = ceil(M / 32), M >= 32
     int sets;                  // row slices per group pair
     float* partial;            // [ngrp][kgrp][set][81][4][64]
     float* bias_partial;       // [ngrp][set][9][4][64], written by the workgroups of k group 0 (null: no bias)
@@ -508,7 +509,7 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
     const int64_t s_lo = a.steps * set / a.sets, s_hi = a.steps * (set + 1) / a.sets;
     // staging: float4 f = t + 768 u of the step's 64 x 36 (32 rows of G, then 32 rows of A).  Columns past
     // the live width (rounded up to 4) re-read column 0: they only reach outputs that are never stored.
-    const float* src[3]; int64_t ld[3]; int waddr[3];
+    const float* src[3]; int64_t ld[3]; int waddr[3]; int srow[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
         const int f = t + T16_THREADS * u;
@@ -517,16 +518,25 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
         const int width = isa ? k_w : n_w;
         const int ceff = col < (width + 3) / 4 * 4 ? col : 0;
         ld[u] = isa ? lda : a.ldg;
+        srow[u] = row;
         src[u] = (isa ? Ab + k_off : a.G + n_off) + (int64_t)row * ld[u] + ceff;
         waddr[u] = (isa * 9 + (col >> 4)) * T16_PANEL + t16_slot(row) * 32 + (col & 15) * 2;
     }
     f32x4 stage[3];
     auto load_step = [&](int64_t s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) stage[u] = *reinterpret_cast<const f32x4*>(src[u] + s * T16_ROWS * ld[u]);
+        for (int u = 0; u < 3; ++u) stage[u] = *reinterpret_cast<const f32x4*>(src[u] + min(s * T16_ROWS, a.M - T16_ROWS) * ld[u]);
     };
-    auto write_step = [&](int b) __attribute__((always_inline)) {
+    // The last step of a matrix whose row count is not a multiple of 32 re-reads the last 32 rows (load_step);
+    // the first `skip` of them belong to the step before and are staged as zeros.
+    auto write_step = [&](int b, int64_t s) __attribute__((always_inline)) {
         unsigned char* base = lds + b * T16_BUF;
+        const int skip = (int)(s * T16_ROWS - min(s * T16_ROWS, a.M - T16_ROWS));        // scalar; 0 for whole steps
+        if (skip > 0) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (srow[u] < skip) stage[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             bf16x4 h, m, l;
@@ -554,7 +564,7 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
 
     if (s_lo < s_hi) {
         load_step(s_lo);
-        write_step(0);
+        write_step(0, s_lo);
         if (s_lo + 1 < s_hi) load_step(s_lo + 1);
     }
     __syncthreads();
@@ -570,7 +580,7 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
             for (int j = 0; j < KT; ++j) x[j][pc] = t16_read(base, pc * T16_PIECE + (9 + k0t + j) * T16_PANEL + raddr);
         }
         // next step's tiles: split and store into the other buffer while the matrix cores work
-        if (s + 1 < s_hi) write_step(b ^ 1);
+        if (s + 1 < s_hi) write_step(b ^ 1, s + 1);
         if (s + 2 < s_hi) load_step(s + 2);
         // six piece products, small terms first: gl*xh, gh*xl, gm*xm, gh*xm, gm*xh, gh*xh
 #define HGV_TN_TERM(GP, XP)                                                                             \
@@ -614,7 +624,6 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tn16(const Tn16Args a) {
 
 struct Tr16Args {
     Tn16Args t;
-    int64_t M;
     float* GW[2]; int64_t ldgw[2];
     float* gbias;
     int accumulate;
@@ -642,23 +651,27 @@ __global__ __launch_bounds__(256) void k_reduce_tn16(const Tr16Args r) {
             grp = (int)(eb / (9 * 256)); off = (int)(eb - (int64_t)grp * 9 * 256);
             src = a.bias_partial + (int64_t)grp * a.sets * (9 * 256) + off; stride = 9 * 256;
         }
-        double s0 = 0.0, s1 = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int b = part;
-        for (; b + 4 < a.sets; b += 8) { s0 += (double)src[(int64_t)b * stride]; s1 += (double)src[(int64_t)(b + 4) * stride]; }
+        for (; b + 28 < a.sets; b += 32) {                 // 8 independent loads in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + 4 * u) * stride];
+            s0 += (double)v[0] + (double)v[4]; s1 += (double)v[1] + (double)v[5];
+            s2 += (double)v[2] + (double)v[6]; s3 += (double)v[3] + (double)v[7];
+        }
         for (; b < a.sets; b += 4) s0 += (double)src[(int64_t)b * stride];
-        s = s0 + s1;
+        s = (s0 + s1) + (s2 + s3);
     }
     sh[part][el] = s;
     __syncthreads();
     if (part != 0 || !live) return;
     double v = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
-    const int64_t covered = a.steps * T16_ROWS;
     const int lane = off & 63, rr = (off >> 6) & 3, tile = off >> 8;
     if (is_bias) {
         if ((lane & 15) != 0) return;                            // every column of a ones product holds the same sum
         const int n = 144 * grp + 16 * tile + 4 * (lane >> 4) + rr;
         if (tile >= 9 || n >= a.N || n >= 144 * (grp + 1)) return;
-        for (int64_t m = covered; m < r.M; ++m) v += (double)a.G[m * a.ldg + n];
         r.gbias[n] = r.accumulate ? r.gbias[n] + (float)v : (float)v;
     } else {
         const int ngrp = grp / a.kgrps, kgrp = grp - ngrp * a.kgrps;
@@ -667,8 +680,6 @@ __global__ __launch_bounds__(256) void k_reduce_tn16(const Tr16Args r) {
         const int nl = 16 * tn + 4 * (lane >> 4) + rr, kl = 16 * tk + (lane & 15);
         const int n = 144 * ngrp + nl, k = 144 * (second ? kgrp - a.kg0 : kgrp) + kl;
         if (n >= a.N || k >= a.K[second]) return;
-        const float* Ab = a.A[second]; const int64_t lda = a.lda[second];
-        for (int64_t m = covered; m < r.M; ++m) v += (double)a.G[m * a.ldg + n] * (double)Ab[m * lda + k];
         float* dst = r.GW[second] + (int64_t)n * r.ldgw[second] + k;
         *dst = r.accumulate ? *dst + (float)v : (float)v;
     }
@@ -682,7 +693,7 @@ Tn16Plan tn16_plan(int64_t M, int N, int K1, int K2) {
     p.ngrps = (int)hgv_cdiv(N, 144);
     p.kg0 = (int)hgv_cdiv(K1, 144);
     p.kgrps = p.kg0 + (K2 > 0 ? (int)hgv_cdiv(K2, 144) : 0);
-    p.steps = (M - 1) / T16_ROWS;                      // the last 1..32 rows are added by the reduction
+    p.steps = hgv_cdiv(M, T16_ROWS);
     const int per = p.ngrps * p.kgrps;
     int64_t sets = cu_count16() / per;
     if (sets < 1) sets = 1;
@@ -790,14 +801,14 @@ extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1
     Tn16Args& a = r.t;
     a.G = G; a.ldg = ldg; a.N = N;
     a.A[0] = A1; a.lda[0] = lda1; a.K[0] = K1; a.A[1] = A2 ? A2 : A1; a.lda[1] = A2 ? lda2 : lda1; a.K[1] = K2;
-    a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.steps = p.steps; a.sets = p.sets;
+    a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.M = M; a.steps = p.steps; a.sets = p.sets;
     a.partial = (float*)ws;
     a.bias_partial = gbias ? (float*)((char*)ws + hgv_align256((size_t)p.ngrps * p.kgrps * p.sets * T16_SET_FLOATS * 4)) : nullptr;
     const size_t lds = 2 * T16_BUF;
     const int rc = raise_lds16(k_gemm_tn16);
     if (rc != HGV_OK) return rc;
     hipLaunchKernelGGL(k_gemm_tn16, dim3((unsigned)(p.ngrps * p.kgrps * p.sets)), dim3(T16_THREADS), lds, stream, a);
-    r.M = M; r.GW[0] = GW1; r.ldgw[0] = ldgw1; r.GW[1] = GW2; r.ldgw[1] = ldgw2; r.gbias = gbias; r.accumulate = accumulate;
+    r.GW[0] = GW1; r.ldgw[0] = ldgw1; r.GW[1] = GW2; r.ldgw[1] = ldgw2; r.gbias = gbias; r.accumulate = accumulate;
     const int64_t elems = (int64_t)p.ngrps * p.kgrps * T16_SET_FLOATS + (gbias ? (int64_t)p.ngrps * 9 * 256 : 0);
     hipLaunchKernelGGL(k_reduce_tn16, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn16");
