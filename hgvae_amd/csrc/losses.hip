@@ -13,66 +13,111 @@ namespace {
 
 constexpr int RED_BLOCKS = 1024;
 
+// Two standard normals from two 32-bit words.  Hardware transcendentals: v_log_f32 is log2, v_sin/v_cos
+// take their argument in revolutions (sin(2 pi x)), which is exactly the Box-Muller angle.
 __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
     const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
-    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.28318530717958647692f * u2, &s, &c);
-    return make_float2(r * c, r * s);
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);            // [0,1)
+    const float r = __builtin_sqrtf(-1.38629436111989f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1), ln = log2 * ln 2
+    return make_float2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }
 
+// Row walker shared by the kernels below: a thread owns the 4-column chunk c = tid % CT of the rows
+// slot, slot + RS, ... (CT = power of two >= chunks per row, RS = 256 / CT row slots per workgroup), so
+// consecutive threads touch consecutive 16-byte pieces and no thread divides by the row width.
+// VEC: rows are 16-byte aligned (pointers aligned, leading dimensions multiples of 4) and a whole chunk
+// may be read even when its tail lies in the row padding.
+struct Walk {
+    int c, slot, RS, CH;
+    bool owns;
+    __device__ __forceinline__ Walk(int ncols, int ct) {
+        CH = (ncols + 3) >> 2; RS = 256 / ct;
+        c = threadIdx.x & (ct - 1); slot = threadIdx.x / ct;
+        owns = c < CH;
+    }
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 ldc(const float* p, int c0, int ncols) {
+    if (VEC) return *reinterpret_cast<const float4*>(p + c0);
+    float4 v;
+    v.x = c0 + 0 < ncols ? p[c0 + 0] : 0.f; v.y = c0 + 1 < ncols ? p[c0 + 1] : 0.f;
+    v.z = c0 + 2 < ncols ? p[c0 + 2] : 0.f; v.w = c0 + 3 < ncols ? p[c0 + 3] : 0.f;
+    return v;
+}
+// stores the live elements of a chunk; with VEC a whole chunk, zeros in the padding
+template <bool VEC>
+__device__ __forceinline__ void stc(float* p, int c0, int ncols, float4 v) {
+    if (VEC) {
+        if (c0 + 1 >= ncols) v.y = 0.f;
+        if (c0 + 2 >= ncols) v.z = 0.f;
+        if (c0 + 3 >= ncols) v.w = 0.f;
+        *reinterpret_cast<float4*>(p + c0) = v;
+    } else {
+        if (c0 + 0 < ncols) p[c0 + 0] = v.x;
+        if (c0 + 1 < ncols) p[c0 + 1] = v.y;
+        if (c0 + 2 < ncols) p[c0 + 2] = v.z;
+        if (c0 + 3 < ncols) p[c0 + 3] = v.w;
+    }
+}
+__device__ __forceinline__ float& el(float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
 // z = mean_k(mean + std * eps_k); eps explicit [n_samples, N, Z] or Philox.  Also writes
-// eps_bar = mean_k eps_k (needed by the backward pass).
-__global__ __launch_bounds__(256) void k_reparam_fwd(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z,
+// eps_bar = mean_k eps_k (needed by the backward pass).  Philox: call k of a chunk yields the k-th
+// draw of its 4 elements (counter = row, chunk, step offset + k).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_reparam_fwd(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z, int ct,
                                                      int n_samples, const float* __restrict__ eps, uint64_t seed,
                                                      uint64_t offset0, const uint64_t* __restrict__ offset_dev,
                                                      float* __restrict__ z, int64_t ldz,
                                                      float* __restrict__ eps_bar) {
+    const Walk w(Z, ct);
+    if (!w.owns) return;
     const int64_t total = N * Z;
     const float inv_n = 1.0f / (float)n_samples;
     const uint64_t offset = offset0 + (offset_dev ? offset_dev[0] : 0ull);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / Z;
-        const int c = (int)(i - row * Z);
-        const float mu = ml[row * ldm + c];
-        const float sd = expf(ml[row * ldm + Z + c]);
-        float acc = 0.f, eacc = 0.f;
-        if (eps) {
-            for (int k = 0; k < n_samples; ++k) {
-                const float e = eps[(int64_t)k * total + i];
-                acc += mu + sd * e;     // same order as the reference's stack().mean(0)
-                eacc += e;
-            }
-        } else {
-            const HgvPhilox ph(seed);
-            for (int k = 0; k < n_samples; k += 4) {
-                const uint4 r = ph((uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)offset + (uint32_t)(k >> 2),
-                                   (uint32_t)(offset >> 32) ^ 0x5EEDu);
+    const HgvPhilox ph(seed);
+    const int c0 = 4 * w.c;
+    for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+        const float* mrow = ml + row * ldm;
+        float4 mu = ldc<VEC>(mrow, c0, Z), sd = ldc<VEC>(mrow + Z, c0, Z);
+        sd.x = expf(sd.x); sd.y = expf(sd.y); sd.z = expf(sd.z); sd.w = expf(sd.w);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), eacc = acc;
+        for (int k = 0; k < n_samples; ++k) {
+            float4 e;
+            if (eps) {
+                e = ldc<VEC>(eps + (int64_t)k * total + row * Z, c0, Z);
+            } else {
+                const uint4 r = ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)w.c << 16),
+                                             (uint32_t)offset + (uint32_t)k, (uint32_t)(offset >> 32) ^ 0x5EEDu);
                 const float2 a = box_muller(r.x, r.y), b = box_muller(r.z, r.w);
-                const float e4[4] = {a.x, a.y, b.x, b.y};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < n_samples) { acc += mu + sd * e4[j]; eacc += e4[j]; }
+                e = make_float4(a.x, a.y, b.x, b.y);
             }
+            // same order as the reference's stack().mean(0)
+            acc.x += mu.x + sd.x * e.x; acc.y += mu.y + sd.y * e.y; acc.z += mu.z + sd.z * e.z; acc.w += mu.w + sd.w * e.w;
+            eacc.x += e.x; eacc.y += e.y; eacc.z += e.z; eacc.w += e.w;
         }
-        z[row * ldz + c] = acc * inv_n;
-        eps_bar[i] = eacc * inv_n;
+        stc<VEC>(z + row * ldz, c0, Z, make_float4(acc.x * inv_n, acc.y * inv_n, acc.z * inv_n, acc.w * inv_n));
+        stc<false>(eps_bar + row * Z, c0, Z, make_float4(eacc.x * inv_n, eacc.y * inv_n, eacc.z * inv_n, eacc.w * inv_n));
     }
 }
 
 // g_mean = gz ; g_log_std = gz * std * eps_bar
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_reparam_bwd(const float* __restrict__ gz, int64_t ldgz,
-                                                     const float* __restrict__ ml, int64_t ldm, int64_t N, int Z,
+                                                     const float* __restrict__ ml, int64_t ldm, int64_t N, int Z, int ct,
                                                      const float* __restrict__ eps_bar, float* __restrict__ gml,
                                                      int64_t ldg) {
-    const int64_t total = N * Z;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / Z;
-        const int c = (int)(i - row * Z);
-        const float g = gz[row * ldgz + c];
-        gml[row * ldg + c] = g;
-        gml[row * ldg + Z + c] = g * expf(ml[row * ldm + Z + c]) * eps_bar[i];
+    const Walk w(Z, ct);
+    if (!w.owns) return;
+    const int c0 = 4 * w.c;
+    for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+        const float4 g = ldc<VEC>(gz + row * ldgz, c0, Z);
+        const float4 ls = ldc<VEC>(ml + row * ldm + Z, c0, Z);
+        const float4 eb = ldc<VEC>(eps_bar + row * Z, c0, Z);
+        stc<VEC>(gml + row * ldg, c0, Z, g);
+        stc<VEC>(gml + row * ldg + Z, c0, Z,
+                   make_float4(g.x * expf(ls.x) * eb.x, g.y * expf(ls.y) * eb.y, g.z * expf(ls.z) * eb.z, g.w * expf(ls.w) * eb.w));
     }
 }
 
@@ -84,30 +129,42 @@ __device__ __forceinline__ void block_reduce_store(float v, float* partial) {
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void k_kl_partial(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z,
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_kl_partial(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z, int ct,
                                                     float* __restrict__ partial) {
-    const int64_t total = N * Z;
+    const Walk w(Z, ct);
+    const int c0 = 4 * w.c;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / Z;
-        const int c = (int)(i - row * Z);
-        const float mu = ml[row * ldm + c], ls = ml[row * ldm + Z + c];
-        const float sd = expf(ls);
-        acc += 1.f + 2.f * ls - mu * mu - sd * sd;
+    if (w.owns) {
+        for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+            float4 mu = ldc<VEC>(ml + row * ldm, c0, Z), ls = ldc<VEC>(ml + row * ldm + Z, c0, Z);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c0 + e < Z) {
+                    const float m = el(mu, e), l = el(ls, e), sd = expf(l);
+                    acc += 1.f + 2.f * l - m * m - sd * sd;
+                }
+            }
+        }
     }
     block_reduce_store(acc, partial);
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_mse_partial(const float* __restrict__ r, int64_t ldr,
-                                                     const float* __restrict__ x, int64_t ldx, int64_t N, int F,
+                                                     const float* __restrict__ x, int64_t ldx, int64_t N, int F, int ct,
                                                      float* __restrict__ partial) {
-    const int64_t total = N * F;
+    const Walk w(F, ct);
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / F;
-        const int c = (int)(i - row * F);
-        const float d = r[row * ldr + c] - x[row * ldx + c];
-        acc += d * d;
+    for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+        for (int c = w.c; c < w.CH; c += ct) {
+            float4 a = ldc<VEC>(r + row * ldr, 4 * c, F), b = ldc<VEC>(x + row * ldx, 4 * c, F);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = el(a, e) - el(b, e);
+                if (4 * c + e < F) acc += d * d;
+            }
+        }
     }
     block_reduce_store(acc, partial);
 }
@@ -124,40 +181,63 @@ __global__ __launch_bounds__(256) void k_finish_sum(const float* __restrict__ pa
 }
 
 // d KL / d mean = mu / N ; d KL / d log_std = (exp(2 ls) - 1) / N, times the upstream scalar *gout
-__global__ __launch_bounds__(256) void k_kl_bwd(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z,
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_kl_bwd(const float* __restrict__ ml, int64_t ldm, int64_t N, int Z, int ct,
                                                 const float* __restrict__ gout, float* __restrict__ gml,
                                                 int64_t ldg, int accumulate) {
-    const int64_t total = N * Z;
+    const Walk w(Z, ct);
+    if (!w.owns) return;
+    const int c0 = 4 * w.c;
     const float s = gout[0] / (float)N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / Z;
-        const int c = (int)(i - row * Z);
-        const float mu = ml[row * ldm + c], ls = ml[row * ldm + Z + c];
-        const float sd = expf(ls);
-        const float gm = s * mu, gl = s * (sd * sd - 1.f);
-        if (accumulate) { gml[row * ldg + c] += gm; gml[row * ldg + Z + c] += gl; }
-        else { gml[row * ldg + c] = gm; gml[row * ldg + Z + c] = gl; }
+    for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+        float4 mu = ldc<VEC>(ml + row * ldm, c0, Z), ls = ldc<VEC>(ml + row * ldm + Z, c0, Z);
+        float4 gm, gl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sd = expf(el(ls, e));
+            el(gm, e) = s * el(mu, e);
+            el(gl, e) = s * (sd * sd - 1.f);
+        }
+        float* gm_p = gml + row * ldg;
+        float* gl_p = gm_p + Z;
+        if (accumulate) {
+            const float4 pm = ldc<VEC>(gm_p, c0, Z), pl = ldc<VEC>(gl_p, c0, Z);
+            gm.x += pm.x; gm.y += pm.y; gm.z += pm.z; gm.w += pm.w;
+            gl.x += pl.x; gl.y += pl.y; gl.z += pl.z; gl.w += pl.w;
+        }
+        stc<VEC>(gm_p, c0, Z, gm);
+        stc<VEC>(gl_p, c0, Z, gl);
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_mse_bwd(const float* __restrict__ r, int64_t ldr, const float* __restrict__ x,
-                                                 int64_t ldx, int64_t N, int F, const float* __restrict__ gout,
+                                                 int64_t ldx, int64_t N, int F, int ct, const float* __restrict__ gout,
                                                  float* __restrict__ gr, int64_t ldg) {
-    const int64_t total = N * F;
+    const Walk w(F, ct);
     const float s = 2.0f * gout[0] / ((float)N * (float)F);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = i / F;
-        const int c = (int)(i - row * F);
-        gr[row * ldg + c] = s * (r[row * ldr + c] - x[row * ldx + c]);
+    for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
+        for (int c = w.c; c < w.CH; c += ct) {
+            const float4 a = ldc<VEC>(r + row * ldr, 4 * c, F), b = ldc<VEC>(x + row * ldx, 4 * c, F);
+            stc<VEC>(gr + row * ldg, 4 * c, F, make_float4(s * (a.x - b.x), s * (a.y - b.y), s * (a.z - b.z), s * (a.w - b.w)));
+        }
     }
 }
 
-int grid_for(int64_t total) {
-    int64_t g = hgv_cdiv(total, 256);
+// threads per row: power of two >= chunks per row, at most 64 (wider rows loop)
+int ct_for(int ncols) {
+    const int ch = (ncols + 3) / 4;
+    int ct = 1;
+    while (ct < ch && ct < 64) ct <<= 1;
+    return ct;
+}
+int grid_rows(int64_t N, int ct) {
+    int64_t g = hgv_cdiv(N, 256 / ct);
     if (g > RED_BLOCKS) g = RED_BLOCKS;
     if (g < 1) g = 1;
     return (int)g;
 }
+bool rows_vec(const float* p, int64_t ld, int ncols) { return hgv_aligned(p, 16) && ld % 4 == 0 && ld >= (ncols + 3) / 4 * 4; }
 
 }  // namespace
 
@@ -170,8 +250,13 @@ extern "C" int hgv_reparam_fwd(const float* ml, int64_t ldm, int64_t N, int Z, i
     HGV_REQUIRE(N >= 0 && Z > 0 && n_samples > 0, HGV_EINVAL, "reparam_fwd: bad sizes");
     if (N == 0) return HGV_OK;
     HGV_REQUIRE(ml && z && eps_bar && ldm >= 2 * Z && ldz >= Z, HGV_EINVAL, "reparam_fwd: null/short buffer");
-    hipLaunchKernelGGL(k_reparam_fwd, dim3(grid_for(N * Z)), dim3(256), 0, stream, ml, ldm, N, Z, n_samples, eps, seed,
-                       offset, offset_dev, z, ldz, eps_bar);
+    const int ct = ct_for(Z);
+    HGV_REQUIRE(ct * 4 >= Z, HGV_EUNSUPPORTED, "reparam_fwd: latent width %d > 256", Z);
+    const bool vec = Z % 4 == 0 && rows_vec(ml, ldm, 2 * Z) && rows_vec(z, ldz, Z) && hgv_aligned(eps_bar, 16) && (!eps || hgv_aligned(eps, 16));
+    if (vec) hipLaunchKernelGGL(k_reparam_fwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, ml, ldm, N, Z, ct, n_samples, eps, seed,
+                                offset, offset_dev, z, ldz, eps_bar);
+    else hipLaunchKernelGGL(k_reparam_fwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, ml, ldm, N, Z, ct, n_samples, eps, seed,
+                            offset, offset_dev, z, ldz, eps_bar);
     HGV_CHECK_LAUNCH("reparam_fwd");
     return HGV_OK;
 }
@@ -181,7 +266,11 @@ extern "C" int hgv_reparam_bwd(const float* gz, int64_t ldgz, const float* ml, i
     HGV_REQUIRE(N >= 0 && Z > 0, HGV_EINVAL, "reparam_bwd: bad sizes");
     if (N == 0) return HGV_OK;
     HGV_REQUIRE(gz && ml && eps_bar && gml && ldm >= 2 * Z && ldg >= 2 * Z && ldgz >= Z, HGV_EINVAL, "reparam_bwd: null/short buffer");
-    hipLaunchKernelGGL(k_reparam_bwd, dim3(grid_for(N * Z)), dim3(256), 0, stream, gz, ldgz, ml, ldm, N, Z, eps_bar, gml, ldg);
+    const int ct = ct_for(Z);
+    HGV_REQUIRE(ct * 4 >= Z, HGV_EUNSUPPORTED, "reparam_bwd: latent width %d > 256", Z);
+    const bool vec = Z % 4 == 0 && rows_vec(ml, ldm, 2 * Z) && rows_vec(gz, ldgz, Z) && rows_vec(gml, ldg, 2 * Z) && hgv_aligned(eps_bar, 16);
+    if (vec) hipLaunchKernelGGL(k_reparam_bwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, gz, ldgz, ml, ldm, N, Z, ct, eps_bar, gml, ldg);
+    else hipLaunchKernelGGL(k_reparam_bwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, gz, ldgz, ml, ldm, N, Z, ct, eps_bar, gml, ldg);
     HGV_CHECK_LAUNCH("reparam_bwd");
     return HGV_OK;
 }
@@ -191,8 +280,11 @@ extern "C" int hgv_kl_fwd(const float* ml, int64_t ldm, int64_t N, int Z, float*
                           hipStream_t stream) {
     HGV_REQUIRE(N > 0 && Z > 0 && ml && out && ws && ldm >= 2 * Z, HGV_EINVAL, "kl_fwd: bad arguments");
     HGV_REQUIRE(ws_bytes >= hgv_loss_ws(), HGV_EWORKSPACE, "kl_fwd: workspace too small");
-    const int g = grid_for(N * Z);
-    hipLaunchKernelGGL(k_kl_partial, dim3(g), dim3(256), 0, stream, ml, ldm, N, Z, (float*)ws);
+    const int ct = ct_for(Z);
+    HGV_REQUIRE(ct * 4 >= Z, HGV_EUNSUPPORTED, "kl_fwd: latent width %d > 256", Z);
+    const int g = grid_rows(N, ct);
+    if (Z % 4 == 0 && rows_vec(ml, ldm, 2 * Z)) hipLaunchKernelGGL(k_kl_partial<true>, dim3(g), dim3(256), 0, stream, ml, ldm, N, Z, ct, (float*)ws);
+    else hipLaunchKernelGGL(k_kl_partial<false>, dim3(g), dim3(256), 0, stream, ml, ldm, N, Z, ct, (float*)ws);
     hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, stream, (const float*)ws, g, -0.5 / (double)N, out);
     HGV_CHECK_LAUNCH("kl_fwd");
     return HGV_OK;
@@ -201,7 +293,10 @@ extern "C" int hgv_kl_fwd(const float* ml, int64_t ldm, int64_t N, int Z, float*
 extern "C" int hgv_kl_bwd(const float* ml, int64_t ldm, int64_t N, int Z, const float* gout, float* gml, int64_t ldg,
                           int accumulate, hipStream_t stream) {
     HGV_REQUIRE(N > 0 && Z > 0 && ml && gout && gml && ldm >= 2 * Z && ldg >= 2 * Z, HGV_EINVAL, "kl_bwd: bad arguments");
-    hipLaunchKernelGGL(k_kl_bwd, dim3(grid_for(N * Z)), dim3(256), 0, stream, ml, ldm, N, Z, gout, gml, ldg, accumulate);
+    const int ct = ct_for(Z);
+    HGV_REQUIRE(ct * 4 >= Z, HGV_EUNSUPPORTED, "kl_bwd: latent width %d > 256", Z);
+    if (Z % 4 == 0 && rows_vec(ml, ldm, 2 * Z) && rows_vec(gml, ldg, 2 * Z)) hipLaunchKernelGGL(k_kl_bwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, ml, ldm, N, Z, ct, gout, gml, ldg, accumulate);
+    else hipLaunchKernelGGL(k_kl_bwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, ml, ldm, N, Z, ct, gout, gml, ldg, accumulate);
     HGV_CHECK_LAUNCH("kl_bwd");
     return HGV_OK;
 }
@@ -211,8 +306,10 @@ extern "C" int hgv_mse_fwd(const float* r, int64_t ldr, const float* x, int64_t 
                            void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(N > 0 && F > 0 && r && x && out && ws && ldr >= F && ldx >= F, HGV_EINVAL, "mse_fwd: bad arguments");
     HGV_REQUIRE(ws_bytes >= hgv_loss_ws(), HGV_EWORKSPACE, "mse_fwd: workspace too small");
-    const int g = grid_for(N * F);
-    hipLaunchKernelGGL(k_mse_partial, dim3(g), dim3(256), 0, stream, r, ldr, x, ldx, N, F, (float*)ws);
+    const int ct = ct_for(F);
+    const int g = grid_rows(N, ct);
+    if (rows_vec(r, ldr, F) && rows_vec(x, ldx, F)) hipLaunchKernelGGL(k_mse_partial<true>, dim3(g), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, (float*)ws);
+    else hipLaunchKernelGGL(k_mse_partial<false>, dim3(g), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, (float*)ws);
     hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, stream, (const float*)ws, g, 1.0 / ((double)N * (double)F), out);
     HGV_CHECK_LAUNCH("mse_fwd");
     return HGV_OK;
@@ -221,7 +318,10 @@ extern "C" int hgv_mse_fwd(const float* r, int64_t ldr, const float* x, int64_t 
 extern "C" int hgv_mse_bwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F,
                            const float* gout, float* gr, int64_t ldg, hipStream_t stream) {
     HGV_REQUIRE(N > 0 && F > 0 && r && x && gout && gr && ldr >= F && ldx >= F && ldg >= F, HGV_EINVAL, "mse_bwd: bad arguments");
-    hipLaunchKernelGGL(k_mse_bwd, dim3(grid_for(N * F)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, gout, gr, ldg);
+    const int ct = ct_for(F);
+    if (rows_vec(r, ldr, F) && rows_vec(x, ldx, F) && rows_vec(gr, ldg, F))
+        hipLaunchKernelGGL(k_mse_bwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg);
+    else hipLaunchKernelGGL(k_mse_bwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg);
     HGV_CHECK_LAUNCH("mse_bwd");
     return HGV_OK;
 }
