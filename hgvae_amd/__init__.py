@@ -7,6 +7,7 @@ from . import _lib  # noqa: F401
 from .data import Batch, CustomGraphDataset, Data, collate_fn  # noqa: F401
 from .graph import Graph, graph_of  # noqa: F401
 from .noise import NoiseTape, manual_seed, use_noise  # noqa: F401
+from .shard import GraphShard  # noqa: F401
 
-__all__ = ["Batch", "CustomGraphDataset", "Data", "collate_fn", "Graph", "graph_of", "NoiseTape", "manual_seed",
+__all__ = ["GraphShard", "Batch", "CustomGraphDataset", "Data", "collate_fn", "Graph", "graph_of", "NoiseTape", "manual_seed",
            "use_noise"]

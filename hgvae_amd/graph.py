@@ -108,6 +108,17 @@ class Graph:
         self._loops: Optional["Graph"] = None
         self._t2f = None
 
+    @classmethod
+    def from_parts(cls, edge_index: torch.Tensor, num_nodes: int, by_dst: _Csr, by_src: Optional[_Csr]) -> "Graph":
+        """Graph around CSR arrays that already exist (e.g. assembled from a packed shard): nothing is sorted."""
+        g = cls.__new__(cls)
+        g.num_nodes, g.num_edges = int(num_nodes), int(edge_index.size(1))
+        g._ei_ref, g._ei_hold = weakref.ref(edge_index), edge_index
+        g.status = torch.zeros(1, dtype=torch.int32, device=edge_index.device)
+        g.by_dst, g._by_src = by_dst, by_src
+        g._inv_deg = g._loops = g._t2f = None
+        return g
+
     @property
     def edge_index(self) -> torch.Tensor:
         ei = self._ei_ref()

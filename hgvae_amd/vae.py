@@ -335,6 +335,13 @@ def _to_device(data, device):
     return data
 
 
+def _edges(model, data):
+    """The batch's ready-made Graph when the loader supplies one (hgvae_amd.shard.GraphShard) and the model
+    takes it in place of edge_index; else the edge_index tensor."""
+    g = getattr(data, "graph", None)
+    return g if g is not None and isinstance(model, SkipconVAE) else data.edge_index
+
+
 def train_vae(model, loader, optimizer, lambda_kl=1.0):
     """One epoch; per batch: forward, SECOND encode, mse + lambda*kl, backward, step
     (gvae/gvae_skipcon.py:159-187).  The running loss stays on the device; one host sync per epoch."""
@@ -344,7 +351,7 @@ def train_vae(model, loader, optimizer, lambda_kl=1.0):
     for data in loader:
         data = _to_device(data, dev)
         optimizer.zero_grad()
-        loss = train_step_loss(model, data.x, data.edge_index, data.batch, lambda_kl)
+        loss = train_step_loss(model, data.x, _edges(model, data), data.batch, lambda_kl)
         loss.backward()
         optimizer.step()
         total += loss.detach()
@@ -369,7 +376,7 @@ def validate_vae(model, loader):
     with torch.no_grad():
         for data in loader:
             data = _to_device(data, dev)
-            total += train_step_loss(model, data.x, data.edge_index, data.batch, 1.0)
+            total += train_step_loss(model, data.x, _edges(model, data), data.batch, 1.0)
     return float(total.item()) / len(loader)
 
 

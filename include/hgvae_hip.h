@@ -52,6 +52,27 @@ int hgv_csr_build(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int
                   int32_t* rowptr, int32_t* col, int32_t* perm, int32_t* status, void* ws, size_t ws_bytes,
                   hgv_stream_t stream);
 
+/* ---- mini-batch assembly on the device from a packed shard of graphs (replaces the per-item torch.load and the Python
+ *      Batch.from_data_list of gvae/gvae_skipcon.py:236-263) ---------------------------------------------------------
+ * The shard is the disjoint union of all graphs of a dataset: node_ptr / edge_ptr [G+1] (first node / edge of every
+ * graph), x_all [Nt, ldx], ei_all [2][e_total] with shard-global node numbers, and per direction the CSR of the union
+ * (hgv_csr_build of ei_all): rowptr_all [Nt+1], col_all, perm_all [e_total].  A batch selects graphs ids[0..B) (any
+ * order, B <= 65535); out_nptr / out_eptr [B+1] are the prefix sums of their node / edge counts (all index arrays on
+ * the device), max_nodes / max_edges the largest count of a selected graph (sizes the launch).
+ * hgv_collate_nodes writes x_out [n_out, ldo] (columns [F, ldo) zeroed), batch_out [n_out] (graph number per node,
+ * nullable) and the batch's CSR row pointers [n_out+1] (nullable); hgv_collate_edges writes ei_out [2][e_out] and the
+ * CSR col / perm arrays of both directions (each group nullable) and the edge attributes [e_out, ea_dim].
+ * The CSR arrays equal hgv_csr_build of ei_out bit for bit: graphs are disjoint, so no sort is needed per batch. */
+int hgv_collate_nodes(const float* x_all, int64_t ldx, int F, const int64_t* node_ptr, const int64_t* edge_ptr,
+                      const int32_t* rowptr_dst_all, const int32_t* rowptr_src_all, const int64_t* ids, int B,
+                      const int64_t* out_nptr, const int64_t* out_eptr, int64_t n_out, int64_t max_nodes, float* x_out,
+                      int64_t ldo, int64_t* batch_out, int32_t* rowptr_dst_out, int32_t* rowptr_src_out, hgv_stream_t stream);
+int hgv_collate_edges(const int64_t* ei_all, int64_t e_total, const int32_t* col_dst_all, const int32_t* perm_dst_all,
+                      const int32_t* col_src_all, const int32_t* perm_src_all, const float* ea_all, int ea_dim,
+                      const int64_t* node_ptr, const int64_t* edge_ptr, const int64_t* ids, int B, const int64_t* out_nptr,
+                      const int64_t* out_eptr, int64_t e_out, int64_t max_edges, int64_t* ei_out, int32_t* col_dst_out, int32_t* perm_dst_out,
+                      int32_t* col_src_out, int32_t* perm_src_out, float* ea_out, hgv_stream_t stream);
+
 /* Stable LSD radix sort of (uint32 key, int32 value) pairs on key bits [bit_lo, bit_hi).
  * vals_in may be null (values = positions).  Used by the per-graph top-k of SAGPooling
  * (autoencoder/vae_with_pool.py:39). */
