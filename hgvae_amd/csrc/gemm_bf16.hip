@@ -35,6 +35,8 @@ struct Geo16 {
     int chunks;          // 32-wide k chunks over the concatenation
     int tiles;           // n tiles (16 columns each)
     int parts, tpp;      // parts along N, n tiles per part (last part may hold fewer)
+    int stream;          // 1: the image does not fit in LDS even in two parts; one part of tpp >= tiles n tiles whose
+                         //    32-wide k chunks are streamed through LDS (k_gemm_nt16s)
 };
 
 __host__ __device__ inline size_t part_bytes16(int tiles_in_part, int chunks) { return (size_t)chunks * 3 * tiles_in_part * 16 * 64; }
@@ -44,11 +46,20 @@ inline bool geo16(int N, int K1, int K2, Geo16* g) {
     g->nb1 = (K1 + 7) / 8; g->nb2 = (K2 + 7) / 8;
     g->chunks = (g->nb1 + g->nb2 + 3) / 4;
     g->tiles = (N + 15) / 16;
+    g->stream = 0;
     // table (chunks x 4 lanes groups x 16 B) + bias row live in LDS next to the image
     for (int parts = 1; parts <= 2; ++parts) {
         const int tpp = (g->tiles + parts - 1) / parts;
         if (tpp <= 9 && part_bytes16(tpp, g->chunks) + (size_t)g->chunks * 64 + 9 * 16 * 4 + 256 <= LDS16_MAX) {
             g->parts = parts; g->tpp = tpp;
+            return true;
+        }
+    }
+    // streamed: two chunk buffers of 3 pieces x (16 tpp) rows x 64 B, tpp = instantiated tile count >= tiles
+    static const int widths[] = {2, 4, 6, 9, 12, 16, 18};
+    for (int w : widths) {
+        if (w >= g->tiles && (size_t)2 * 3 * w * 1024 + (size_t)g->chunks * 64 + (size_t)w * 64 + 256 <= LDS16_MAX) {
+            g->parts = 1; g->tpp = w; g->stream = 1;
             return true;
         }
     }
@@ -342,6 +353,117 @@ __global__ __launch_bounds__(64 * nt16_waves<NT0>()) void k_gemm_nt16_pair(const
     else nt16_body<NT1, nt16_ring<NT1>()>(a, lds_raw, 1, (int)blockIdx.x - a.wgs0, (int)gridDim.x - a.wgs0);
 }
 
+// ------------------------------------------------------------------------------------------
+// Same product for weights whose split image does not fit in LDS (hidden width 256): the image is
+// streamed.  A workgroup of 12 waves owns blocks of 12 row tiles (one per wave, all NT n tiles of it);
+// for every 32-wide k chunk the waves multiply from one LDS buffer while all threads copy the next
+// chunk of the image (3 pieces x 16 NT rows x 64 B, contiguous in the packed image and L2-resident)
+// into the other; one barrier per chunk.  A is loaded and split per wave as in k_gemm_nt16, one chunk
+// ahead.
+template <int NT>
+__global__ __launch_bounds__(768) void k_gemm_nt16s(const Nt16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const Geo16& g = a.g;
+    const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int ROWS = NT * 16, CHUNK_BYTES = 3 * ROWS * 64, UNITS = CHUNK_BYTES / 16, UPT = (UNITS + 767) / 768;
+    int4* tab = reinterpret_cast<int4*>(lds_raw + 2 * CHUNK_BYTES);
+    float* bias_s = reinterpret_cast<float*>(lds_raw + 2 * CHUNK_BYTES + (size_t)g.chunks * 64);
+    for (int e = t; e < g.chunks * 4; e += 768) {
+        int second = 0, col = 0; int64_t ld = a.lda1;
+        if (e < g.nb1) { col = 8 * e; }
+        else if (e < g.nb1 + g.nb2) { second = 1; col = 8 * (e - g.nb1); ld = a.lda2; }
+        const int c0 = (int)min((int64_t)col, ld - 4), c1 = (int)min((int64_t)col + 4, ld - 4);
+        tab[e] = make_int4(c0 * 4, c1 * 4, second, 0);
+    }
+    for (int e = t; e < ROWS; e += 768) bias_s[e] = (a.bias && e < g.N) ? a.bias[e] : 0.f;
+
+    const f32x4* img = reinterpret_cast<const f32x4*>(a.Wp);
+    f32x4 wst[UPT];
+    auto w_load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) wst[u] = img[(size_t)c * UNITS + min(t + 768 * u, UNITS - 1)];
+    };
+    auto w_store = [&](int b) __attribute__((always_inline)) {
+        f32x4* dst = reinterpret_cast<f32x4*>(lds_raw + b * CHUNK_BYTES);
+#pragma unroll
+        for (int u = 0; u < UPT; ++u)
+            if (t + 768 * u < UNITS) dst[t + 768 * u] = wst[u];
+    };
+    const int64_t nblocks = (a.ntiles + 11) / 12;
+    const int chunks = g.chunks;
+    const int wlane = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
+
+    w_load(0);
+    w_store(0);
+    __syncthreads();                       // table, bias and the first chunk are in place
+
+    // A of (row block, chunk): two 16-byte halves of the lane's 8 consecutive k
+    f32x4 a_nx[2];
+    auto a_load = [&](int64_t rb, int c) __attribute__((always_inline)) {
+        const int64_t row = min((rb * 12 + wib) * 16 + i, a.M - 1);
+        const int4 e = tab[c * 4 + kq];
+        const char* p = e.z ? reinterpret_cast<const char*>(a.A2 + row * a.lda2) : reinterpret_cast<const char*>(a.A1 + row * a.lda1);
+        a_nx[0] = *reinterpret_cast<const f32x4*>(p + e.x);
+        a_nx[1] = *reinterpret_cast<const f32x4*>(p + e.y);
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < nblocks) a_load(blockIdx.x, 0);
+    for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = *reinterpret_cast<const f32x4*>(&bias_s[16 * n + 4 * kq]);
+        for (int c = 0; c < chunks; ++c) {
+            const int cn = c + 1 < chunks ? c + 1 : 0;
+            w_load(cn);                                      // next chunk of the image (cyclic): global -> registers
+            bf16x8 ah, am, al;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 h, m, l;
+                split3(a_nx[j >> 2][j & 3], h, m, l);
+                ah[j] = h; am[j] = m; al[j] = l;
+            }
+            // A of the next step: next chunk of this block, or chunk 0 of the workgroup's next block (clamped at the end)
+            {
+                const int64_t rbn = c + 1 < chunks ? rb : (rb + gridDim.x < nblocks ? rb + gridDim.x : rb);
+                a_load(rbn, cn);
+            }
+            const unsigned char* base = lds_raw + buf * CHUNK_BYTES + wlane;
+            constexpr int GS = 3;
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += GS) {
+                bf16x8 wh[GS], wm[GS], wl[GS];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    if (n0 + j < NT) {
+                        const unsigned char* w = base + (size_t)(n0 + j) * 16 * 64;
+                        wh[j] = *reinterpret_cast<const bf16x8*>(w);
+                        wm[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)ROWS * 64);
+                        wl[j] = *reinterpret_cast<const bf16x8*>(w + (size_t)2 * ROWS * 64);
+                    }
+                }
+#define HGV_S_TERM(WP, AP)                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < GS; ++j)                                                    \
+                    if (n0 + j < NT) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WP[j], AP, acc[n0 + j], 0, 0, 0);
+                HGV_S_TERM(wl, ah) HGV_S_TERM(wh, al) HGV_S_TERM(wm, am) HGV_S_TERM(wm, ah) HGV_S_TERM(wh, am) HGV_S_TERM(wh, ah)
+#undef HGV_S_TERM
+            }
+            w_store(buf ^ 1);
+            buf ^= 1;
+            __syncthreads();
+        }
+        const int64_t tile = rb * 12 + wib;
+        const int64_t row = tile * 16 + i;
+        if (tile < a.ntiles && row < a.M) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = n * 16 + 4 * kq;
+                if (col < a.ldc) *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = acc[n];
+            }
+        }
+    }
+}
+
 int cu_count16() {
     static int cached[64] = {0};
     int dev = 0;
@@ -394,6 +516,31 @@ int launch_nt16_part(const Nt16Args& a, int part, int nt, size_t lds, hipStream_
         case 7: return launch_nt16<7>(a, part, lds, st);
         case 8: return launch_nt16<8>(a, part, lds, st);
         default: return launch_nt16<9>(a, part, lds, st);
+    }
+}
+
+template <int NT>
+int launch_nt16s_nt(const Nt16Args& a, hipStream_t st) {
+    auto kern = k_gemm_nt16s<NT>;
+    const int rc = raise_lds16(kern);
+    if (rc != HGV_OK) return rc;
+    const size_t lds = (size_t)2 * 3 * NT * 1024 + (size_t)a.g.chunks * 64 + (size_t)NT * 64;
+    int64_t blocks = hgv_cdiv(a.ntiles, 12);
+    if (blocks > cu_count16()) blocks = cu_count16();
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), lds, st, a);
+    return HGV_OK;
+}
+
+int launch_nt16s(const Nt16Args& a, hipStream_t st) {
+    switch (a.g.tpp) {
+        case 2: return launch_nt16s_nt<2>(a, st);
+        case 4: return launch_nt16s_nt<4>(a, st);
+        case 6: return launch_nt16s_nt<6>(a, st);
+        case 9: return launch_nt16s_nt<9>(a, st);
+        case 12: return launch_nt16s_nt<12>(a, st);
+        case 16: return launch_nt16s_nt<16>(a, st);
+        case 18: return launch_nt16s_nt<18>(a, st);
+        default: return HGV_EUNSUPPORTED;
     }
 }
 
@@ -761,7 +908,9 @@ extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float*
     const size_t lds = part_bytes16(a.g.tpp, a.g.chunks) + (size_t)a.g.chunks * 64 + 9 * 16 * 4;
     // a part holds exactly its n tiles; the rows of A are streamed once per part
     int rc;
-    if (a.g.parts == 1) {
+    if (a.g.stream) {
+        rc = launch_nt16s(a, stream);
+    } else if (a.g.parts == 1) {
         rc = launch_nt16_part(a, 0, a.g.tiles, lds, stream);
     } else {
         const int nt1 = a.g.tiles - a.g.tpp;

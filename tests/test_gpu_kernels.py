@@ -421,6 +421,8 @@ def test_sag_pooling_matches_oracle(scorer):
 GEMM_SHAPES = [  # (M, K1, K2, N)
     (1, 6, None, 1), (127, 28, None, 138), (129, 138, 138, 138), (1000, 105, 105, 138), (777, 138, 138, 56),
     (513, 276, 276, 56), (300, 138, 138, 276), (2049, 60, 60, 256), (640, 34, None, 138), (5000, 138, None, 105),
+    # hidden width 256 (attention variant): the split weight image is streamed through LDS chunk by chunk
+    (2500, 256, 256, 256), (191, 256, None, 256), (193, 105, 105, 256), (12 * 16 * 3 + 5, 288, 288, 138), (40, 256, 256, 200),
 ]
 
 
@@ -464,7 +466,7 @@ def test_dual_linear_forward_backward(shape, projection_kind):
 
 @pytest.mark.parametrize("kind", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("shape", [(160_984, 138, 138, 138), (160_984, 105, 105, 138), (131_072 + 7, 138, None, 56),
-                                   (70_001, 276, None, 138)])
+                                   (70_001, 276, None, 138), (100_003, 256, 256, 256)])
 def test_projection_kernels_at_benchmark_rows(shape, kind):
     """Row counts of the benchmark shard: every wave of the resident-weight kernel streams several
     row tiles (the load ring runs across tile boundaries) and the weight-gradient kernel splits the

@@ -32,6 +32,8 @@ def main():
     dev = torch.device("cuda:0")
     m = int(os.environ.get("M", 160984))
     shapes = [(138, 138, 138), (138, None, 138), (105, 105, 138), (138, 138, 56), (276, None, 138), (28, None, 138)]
+    if os.environ.get("WIDE"):     # hidden width 256 (attention variant)
+        shapes = [(256, 256, 256), (256, None, 256), (105, 105, 256), (256, None, 56)]
     only = os.environ.get("ONLY")
     if only is not None:
         shapes = [shapes[int(only)]]
