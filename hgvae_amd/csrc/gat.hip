@@ -92,6 +92,68 @@ __global__ __launch_bounds__(256) void k_gat_bwd_dot(const int32_t* __restrict__
     }
 }
 
+// The same dot products with 16-byte accesses: a group of L lanes owns a row, lane l keeps the 4-float
+// chunks l, l + L, ... (CPL of them) of g[i,:] in registers; neighbour indices are fetched L at a time
+// and broadcast; two edges are in flight per group and reduced together.  Needs 16-byte aligned rows.
+template <int CPL>
+__global__ __launch_bounds__(128) void k_gat_bwd_dot4(const int32_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, int64_t N,
+                                                      const float* __restrict__ g, int64_t ldg,
+                                                      const float* __restrict__ xw, int64_t ldx, int C, int lshift,
+                                                      float* __restrict__ dad) {
+    const int lane = threadIdx.x & 63;
+    const int L = 1 << lshift;
+    const int lr = lane & (L - 1);
+    const int64_t wave = (int64_t)hgv_xcd_remap(blockIdx.x, gridDim.x) * 2 + (threadIdx.x >> 6);
+    const int64_t row = wave * (64 >> lshift) + (lane >> lshift);
+    if (row >= N) return;
+    const int nchunks = (C + 3) >> 2;
+    float4 gr[CPL];
+    int coff[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lr + q * L;
+        coff[q] = (c < nchunks ? c : 0) * 4;
+        float4 v = *reinterpret_cast<const float4*>(g + row * ldg + coff[q]);
+        // columns past C (row padding) and chunks past the row count as zeros
+        if (c >= nchunks) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (coff[q] + 1 >= C) v.y = 0.f;
+        if (coff[q] + 2 >= C) v.z = 0.f;
+        if (coff[q] + 3 >= C) v.w = 0.f;
+        gr[q] = v;
+    }
+    const int start = rowptr[row], end = rowptr[row + 1];
+    for (int base = start; base < end; base += L) {
+        const int k = base + lr;
+        const int my_col = k < end ? col[k] : 0;
+        const int cnt = min(L, end - base);
+        for (int j = 0; j < cnt; j += 2) {
+            const float* r0 = xw + (int64_t)__shfl(my_col, j, L) * ldx;
+            const float* r1 = xw + (int64_t)__shfl(my_col, min(j + 1, cnt - 1), L) * ldx;
+            float4 v0[CPL], v1[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                v0[q] = *reinterpret_cast<const float4*>(r0 + coff[q]);
+                v1[q] = *reinterpret_cast<const float4*>(r1 + coff[q]);
+            }
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                a0 += gr[q].x * v0[q].x + gr[q].y * v0[q].y + gr[q].z * v0[q].z + gr[q].w * v0[q].w;
+                a1 += gr[q].x * v1[q].x + gr[q].y * v1[q].y + gr[q].z * v1[q].z + gr[q].w * v1[q].w;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                if (o < L) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+            }
+            if (lr == 0) {
+                dad[base + j] = a0;
+                if (j + 1 < cnt) dad[base + j + 1] = a1;
+            }
+        }
+    }
+}
+
 // softmax + dropout + leaky-relu backward per row:
 //   dalpha_k = dad[k] * keep_k ; S = sum_k alpha_k dalpha_k ; de_k = alpha_k (dalpha_k - S)
 //   dl_k = de_k * (raw_k > 0 ? 1 : slope) ; da_dst[i] = sum_k dl_k ; dl[k] is scattered to sources later
@@ -153,11 +215,35 @@ extern "C" int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, int64_t N,
     HGV_REQUIRE(rowptr && col && g && xw && a_src && a_dst && alpha && alpha_drop && dad && dl && da_dst, HGV_EINVAL,
                 "gat_bwd: null buffer");
     HGV_REQUIRE(ldg >= C && ldx >= C, HGV_EINVAL, "gat_bwd: leading dimension < C");
-    int ls = 0;
-    while ((1 << ls) < C && ls < 6) ++ls;
-    const int rows_per_block = 4 * (64 >> ls);
-    hipLaunchKernelGGL(k_gat_bwd_dot, dim3((unsigned)hgv_cdiv(N, rows_per_block)), dim3(256), 0, stream, rowptr, col, N,
-                       g, ldg, xw, ldx, C, ls, dad);
+    const int nchunks = (C + 3) / 4;
+    if (hgv_aligned(g, 16) && hgv_aligned(xw, 16) && ldg % 4 == 0 && ldx % 4 == 0 && ldg >= nchunks * 4 && ldx >= nchunks * 4 &&
+        nchunks <= 256) {
+        // lanes per row (>= 8 unless the row is shorter) x chunks per lane (<= 4): fewest lane slots
+        int ls = 0, cpl = 4;
+        int64_t best = -1;
+        for (int l = 0; l <= 6; ++l) {
+            const int Lc = 1 << l;
+            if (Lc < 8 && Lc < nchunks) continue;
+            int c = (int)hgv_cdiv(nchunks, Lc);
+            if (c > 4) continue;
+            if (c < 1) c = 1;
+            if (best < 0 || (int64_t)Lc * c < best) { best = (int64_t)Lc * c; ls = l; cpl = c; }
+        }
+        const int rows_per_block = 2 * (64 >> ls);
+        const dim3 grid((unsigned)hgv_cdiv(N, rows_per_block)), block(128);
+        switch (cpl) {
+            case 1: hipLaunchKernelGGL(k_gat_bwd_dot4<1>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
+            case 2: hipLaunchKernelGGL(k_gat_bwd_dot4<2>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
+            case 3: hipLaunchKernelGGL(k_gat_bwd_dot4<3>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
+            default: hipLaunchKernelGGL(k_gat_bwd_dot4<4>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
+        }
+    } else {
+        int ls = 0;
+        while ((1 << ls) < C && ls < 6) ++ls;
+        const int rows_per_block = 4 * (64 >> ls);
+        hipLaunchKernelGGL(k_gat_bwd_dot, dim3((unsigned)hgv_cdiv(N, rows_per_block)), dim3(256), 0, stream, rowptr, col, N,
+                           g, ldg, xw, ldx, C, ls, dad);
+    }
     hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((unsigned)hgv_cdiv(N * GL, 256)), dim3(256), 0, stream, rowptr, col, N,
                        a_src, ld_src, a_dst, ld_dst, slope, alpha, alpha_drop, dad, dl, da_dst);
     HGV_CHECK_LAUNCH("gat_bwd");
