@@ -5,4 +5,4 @@
 from .data import CustomGraphDataset, collate_fn  # noqa: F401
 from .vae import SkipconVAE as VAE  # noqa: F401
 from .vae import PoolGraph, PoolUnpoolGraph  # noqa: F401
-from .vae import compute_rmsd, test_vae_rmsd, train_vae, validate_vae  # noqa: F401
+from .vae import compute_rmsd, node_embeddings, test_vae_rmsd, train_vae, validate_vae  # noqa: F401

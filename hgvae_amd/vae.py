@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import functional as Fn
-from .graph import as_padded, graph_of
+from .graph import Graph, as_padded, graph_of
 from .data import Data
 from .nn import GATConv, GCNConv, GraphConv, SAGEConv, SAGPooling
 
@@ -394,3 +394,17 @@ def test_vae_rmsd(model, loader):
 
 
 test_vae_rmsd.__test__ = False  # not a pytest test
+
+def node_embeddings(model, x, edge_index):
+    """Per-node latent embeddings of one graph for the clustering step of the reference
+    (gvae/gvae_skipcon.py:333-339: eval mode, no grad, ``encode`` then ``reparameterize``); returns the
+    [N, Z] tensor on the model's device (the reference moves it to numpy for scipy / sklearn)."""
+    was_training = model.training
+    model.eval()
+    dev = model._device()
+    try:
+        with torch.no_grad():
+            enc = model.encode(x.to(dev), edge_index if isinstance(edge_index, Graph) else edge_index.to(dev))
+            return model.reparameterize(enc[-2], enc[-1]).contiguous()
+    finally:
+        model.train(was_training)

@@ -121,6 +121,30 @@ def test_skipcon_eval_forward_matches_oracle():
     close(rec, rec_ref, FWD_RTOL, what="reconstruction")
 
 
+def test_node_embeddings_match_oracle():
+    """Embedding export of the clustering step (gvae/gvae_skipcon.py:333-339): eval encode + reparameterize."""
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from hgvae_amd.vae import SkipconVAE, node_embeddings
+    gen = torch.Generator().manual_seed(4)
+    ei, n, batch = path_batch([138])
+    x = torch.randn(n, 60, generator=gen)
+    torch.manual_seed(4)
+    ref = OM.SkipconVAE(60, 138, 28)
+    randomize_bn(ref, gen)
+    ref.eval()
+    eps = torch.randn(10, n, 28, generator=gen)
+    with torch.no_grad():
+        enc = ref.encode(x, ei, O.NoiseTape([]))
+        z_ref = OM.reparameterize(enc[-2], enc[-1], 10, O.NoiseTape([eps]))
+    mod = SkipconVAE(60, 138, 28)
+    mod.load_state_dict(ref.state_dict())
+    mod = mod.to(torch.device("cuda:0")).train()
+    with use_noise(NoiseTape([eps])):
+        z = node_embeddings(mod, x, ei)
+    assert mod.training and tuple(z.shape) == (n, 28)
+    close(z, z_ref, FWD_RTOL, what="embeddings")
+
+
 def test_train_vae_loop_runs_and_learns():
     """train_vae / validate_vae / test_vae_rmsd drive a loader exactly like the reference's loops."""
     from hgvae_amd import Batch, Data
