@@ -121,6 +121,40 @@ def test_skipcon_eval_forward_matches_oracle():
     close(rec, rec_ref, FWD_RTOL, what="reconstruction")
 
 
+def test_fork_sums_gradients_in_padded_layout():
+    """functional.fork: two consumers of one tensor; the backward sum equals autograd's and stays 16-byte aligned."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import ld_of
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    x0 = torch.randn(301, 138, generator=gen)
+    w1, w2 = torch.randn(138, 7, generator=gen).to(dev), torch.randn(138, 5, generator=gen).to(dev)
+    seen = {}
+
+    def run(forked):
+        x = x0.to(dev).requires_grad_(True)
+        y = x * 1.5
+        if forked:
+            y.register_hook(lambda g: seen.update(ld=ld_of(g)))
+            a, b = Fn.fork(y)
+        else:
+            a = b = y
+        ((a @ w1).sin().sum() + (b @ w2).cos().sum()).backward()
+        return x.grad
+
+    close(run(True), run(False), 1e-6, what="fork gradient")
+    assert seen["ld"] % 4 == 0 and seen["ld"] >= 138
+    # one consumer only: the other gradient is absent, nothing is added
+    x = x0.to(dev).requires_grad_(True)
+    a, _ = Fn.fork(x * 2.0)
+    a.sum().backward()
+    assert torch.equal(x.grad, torch.full_like(x.grad, 2.0))
+    # no grad mode / no grad needed: plain pass-through
+    t = x0.to(dev)
+    p, q = Fn.fork(t)
+    assert p is t and q is t
+
+
 def test_node_embeddings_match_oracle():
     """Embedding export of the clustering step (gvae/gvae_skipcon.py:333-339): eval encode + reparameterize."""
     from hgvae_amd.noise import NoiseTape, use_noise
