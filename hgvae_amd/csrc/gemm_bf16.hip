@@ -166,7 +166,6 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
     const int wib = __builtin_amdgcn_readfirstlane(t >> 6), wpb = blockDim.x >> 6;
     const int t0 = part * g.tpp;                                   // first n tile of the part; it holds exactly NT tiles
     const int rows = g.tpp * 16;                                   // rows per piece image (parts are stored with tpp tiles)
-    __bf16* Wl = reinterpret_cast<__bf16*>(lds_raw);
     const size_t img = part_bytes16(g.tpp, g.chunks);
     int4* tab = reinterpret_cast<int4*>(lds_raw + img);            // [chunks][4]: byte offsets of the two halves, source
     float* bias_s = reinterpret_cast<float*>(lds_raw + img + (size_t)g.chunks * 64);
