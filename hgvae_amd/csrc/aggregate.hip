@@ -215,7 +215,8 @@ extern "C" int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_
                            const float* add, int64_t ldadd, float* out, int64_t ldo, hipStream_t stream) {
     HGV_REQUIRE(n_rows >= 0 && F >= 0, HGV_EINVAL, "agg_fwd: negative size");
     if (n_rows == 0 || F == 0) return HGV_OK;
-    HGV_REQUIRE(rowptr && col && x && out, HGV_EINVAL, "agg_fwd: null buffer");
+    // col may be null for a graph without edges (an empty tensor has no storage): no row then dereferences it
+    HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd: null buffer");
     HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd: leading dimension < F");
     HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd: bad row_mode");
     AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo};

@@ -87,7 +87,7 @@ int hgv_sort_pairs_u32(const uint32_t* keys_in, const int32_t* vals_in, int64_t 
  *   rs_i: row_mode 0 -> 1; 1 -> 1/max(row length, 1) (true division); 2 -> row_scale[i]
  *   w_k = edge_w[k] (nullable) * nbr_w[col[k]] (nullable)
  * Rows are summed in CSR order; the unweighted result is bit-identical to a sequential
- * scatter_add_ in stable edge order. */
+ * scatter_add_ in stable edge order.  col may be null for a graph without edges. */
 int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx, int F,
                 int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w, const float* add,
                 int64_t ldadd, float* out, int64_t ldo, hgv_stream_t stream);
