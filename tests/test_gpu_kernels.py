@@ -526,7 +526,9 @@ def test_projection_kernels_at_benchmark_rows(shape, kind):
 
 @pytest.mark.parametrize("m,n,k1,k2", [(1, 5, 3, 2), (4, 16, 16, 16), (5, 17, 33, 7), (37, 138, 138, 28), (1000, 56, 138, 138),
                                        (4099, 138, 105, 105), (3001, 276, 138, 6), (2500, 1, 276, 138), (9000, 256, 256, 256),
-                                       (6000, 138, 276, 138), (5000, 150, 144, 145)])
+                                       (6000, 138, 276, 138), (5000, 150, 144, 145),
+                                       # the smallest row counts the bf16 kernel takes (one to a few 32-row steps per workgroup, partial last step)
+                                       (128, 138, 138, 138), (130, 138, 138, 138), (255, 144, 144, 144), (257, 138, 105, 138)])
 def test_weight_gradient_pair_small_shapes(m, n, k1, k2):
     """hgv_gemm_tn2 on ragged shapes (rows not a multiple of 4, widths off the tile sizes, different K per source)."""
     from hgvae_amd import functional as Fn
