@@ -66,3 +66,35 @@ def test_batch_norm_single_row_raises_like_torch():
     bn = torch.nn.BatchNorm1d(8).to(dev()).train()
     with pytest.raises(ValueError):
         Fn.bn_act(torch.randn(1, 8, device=dev()), bn, True, 0.5, True)
+
+
+@pytest.mark.parametrize("conv", ["graphconv", "gcn"])
+def test_graphconv_and_gcn_without_edges(conv):
+    """GraphConv: out = lin_root(x) + bias; GCNConv: only the self loop remains, out = x W^T + b."""
+    from hgvae_amd import nn as N
+    torch.manual_seed(1)
+    ref = O.GraphConv(6, 1) if conv == "graphconv" else O.GCNConv(6, 1)
+    mine = N.GraphConv(6, 1) if conv == "graphconv" else N.GCNConv(6, 1)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev())
+    x = torch.randn(9, 6)
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    assert torch.allclose(mine(x.to(dev()), ei.to(dev())).cpu(), ref(x, ei), rtol=1e-5, atol=1e-6)
+
+
+def test_sag_pooling_single_node_and_edgeless_graphs():
+    """k = ceil(0.5 n): a one-node graph keeps its node, an edgeless graph pools by score alone."""
+    from hgvae_amd import nn as N
+    torch.manual_seed(2)
+    ref = O.SAGPooling(8, ratio=0.5)
+    mine = N.SAGPooling(8, ratio=0.5)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(dev())
+    x = torch.randn(1 + 5 + 4, 8)
+    batch = torch.tensor([0] + [1] * 5 + [2] * 4)
+    ei = torch.tensor([[6, 7, 8], [7, 8, 9]])                   # graph 0: one node; graph 1: no edges; graph 2: a path
+    want = ref(x, ei, None, batch)
+    got = mine(x.to(dev()), ei.to(dev()), None, batch.to(dev()))
+    assert torch.equal(got[4].cpu(), want[4])                    # perm
+    assert torch.allclose(got[0].cpu(), want[0], rtol=1e-5, atol=1e-6)
+    assert torch.equal(got[1].cpu(), want[1]) and torch.equal(got[3].cpu(), want[3])
