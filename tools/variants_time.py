@@ -7,6 +7,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hgvae_amd  # noqa: E402
 from hgvae_amd import synthetic  # noqa: E402
 from hgvae_amd import functional as Fn  # noqa: E402
 from hgvae_amd.optim import FlatAdam  # noqa: E402
@@ -31,6 +32,7 @@ def main():
     for name in which:
         make, batch, lossfn = cases[name]
         torch.manual_seed(0)
+        hgvae_amd.manual_seed(int(os.environ.get("NOISE_SEED", "0")))     # same dropout / eps stream whatever ran before
         model = make().to(dev).train()
         opt = FlatAdam(model.parameters(), lr=1e-3)
 
