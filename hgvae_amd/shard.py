@@ -43,6 +43,8 @@ class GraphShard:
         self.numerical_indices = list(numerical_indices) if numerical_indices is not None else None
         if int(self._edge_ptr_host[-1]) != self.edge_index.size(1) or int(self._node_ptr_host[-1]) != x.size(0):
             raise _lib.HgvError("node_ptr / edge_ptr do not match the packed arrays")
+        if self.edge_index.size(1) >= 2 ** 31 or x.size(0) >= 2 ** 31:
+            raise _lib.HgvError("a shard holds at most 2^31 - 1 nodes and edges (int32 CSR); split the dataset into several shards")
         # CSR of the whole union, once: every batch takes its segments from here
         self.graph = Graph(self.edge_index, x.size(0))
         self.graph.by_src
