@@ -32,6 +32,10 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             local_rank = local_rank % torch.cuda.device_count()
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # per-rank dropout / eps streams: the Philox counters are (row, chunk, offset), so ranks sharing one
+        # seed would draw identical noise for the same positions of their shards
+        from . import noise
+        noise.manual_seed(noise.DEFAULT_SEED + rank)
     return rank, world, local_rank
 
 

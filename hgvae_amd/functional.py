@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from .graph import Graph, as_padded, ld_of, new_padded, rowmajor
+from .graph import Graph, as_padded, is_vec4, ld_of, new_padded, rowmajor
 from .noise import current_noise
 
 _ws_cache: "dict[tuple, torch.Tensor]" = {}
@@ -33,14 +33,21 @@ def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
 # neighbour aggregation
 # --------------------------------------------------------------------------------------
 class LaunchProbe:
-    """Optional per-launch timing of the aggregation kernel with events on the launching stream."""
+    """Optional per-launch timing (events on the launching stream) of the aggregation kernel and of the
+    projection products: records are ``(kind, shape, start, end)`` with kind "agg" / "agg_w" (shape
+    ``(rows, F, E)``), "nt" (``(M, K, N)``: C[M,N] = A[M,K] W^T) or "tn" (``(M, N, K)``: GW[N,K] = G^T A)."""
 
     def __init__(self):
-        self.records = []  # (n_rows, F, E, weighted, start_event, end_event)
+        self.records = []
 
-    def durations_ms(self):
+    def add(self, kind, shape):
+        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.append((kind, shape, s, t))
+        return s, t
+
+    def durations_ms(self, kind=None):
         torch.cuda.synchronize()
-        return [(n, f, e, w, s.elapsed_time(t)) for (n, f, e, w, s, t) in self.records]
+        return [(k, shape, s.elapsed_time(t)) for (k, shape, s, t) in self.records if kind is None or k == kind]
 
 
 _probe: Optional[LaunchProbe] = None
@@ -53,11 +60,11 @@ def set_probe(probe: Optional[LaunchProbe]) -> None:
 
 def _agg_launch(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out):
     if _probe is not None:
-        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        weighted = edge_w is not None or nbr_w is not None
+        s, t = _probe.add("agg_w" if weighted else "agg", (n_rows, F, csr.col.numel()))
         s.record()
         _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out)
         t.record()
-        _probe.records.append((n_rows, F, csr.col.numel(), edge_w is not None or nbr_w is not None, s, t))
         return
     _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out)
 
@@ -243,6 +250,9 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     xa / xb must already be in the padded layout."""
     m = xa.size(0)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
+    ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
+    if ev:
+        ev[0].record()
     if img.kind == "bf16x6":
         _lib.call("hgv_gemm_nt16", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
                   ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
@@ -251,6 +261,8 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
         _lib.call("hgv_gemm_nt_packed", xa.data_ptr(), ld_of(xa), xa.size(1), img.a.data_ptr(),
                   _lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0,
                   _lib.ptr(img.b), _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
+    if ev:
+        ev[1].record()
     return out
 
 
@@ -303,14 +315,19 @@ def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out
     if accumulate and (out is None or (want_bias and bias_out is None)):
         raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
     gb = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
+    ev = _probe.add("tn", (m, n, k)) if _probe is not None else None
+    if ev:
+        ev[0].record()
     if _tn16_ok(m, n, k, 0, g, x):
         ws = _workspace(_lib.load().hgv_gemm_tn16_ws(m, n, k, 0), g.device, "gemm_tn")
         _lib.call("hgv_gemm_tn16", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, gw.data_ptr(), gw.stride(0),
                   None, 0, 0, None, 0, m, _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
-        return gw, gb
-    ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
-    _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), gw.stride(0),
-              _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+    else:
+        ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
+        _lib.call("hgv_gemm_tn", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, m, gw.data_ptr(), gw.stride(0),
+                  _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+    if ev:
+        ev[1].record()
     return gw, gb
 
 
@@ -331,9 +348,14 @@ def _gemm_tn2(g, xa, xb, want_bias: bool, out_a=None, out_b=None, bias_out=None,
     gbias = (bias_out if bias_out is not None else torch.empty(n, dtype=torch.float32, device=g.device)) if want_bias else None
     tn16 = _tn16_ok(m, n, ka, kb, g, xa, xb)
     ws = _workspace((_lib.load().hgv_gemm_tn16_ws if tn16 else _lib.load().hgv_gemm_tn2_ws)(m, n, ka, kb), g.device, "gemm_tn")
+    ev = _probe.add("tn", (m, n, ka + kb)) if _probe is not None else None
+    if ev:
+        ev[0].record()
     _lib.call("hgv_gemm_tn16" if tn16 else "hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
               xb.data_ptr(), ld_of(xb), kb, gb_.data_ptr(), gb_.stride(0), m, _lib.ptr(gbias), 1 if accumulate else 0,
               ws.data_ptr(), ws.numel(), _lib.stream())
+    if ev:
+        ev[1].record()
     return ga, gb_, gbias
 
 
@@ -589,7 +611,9 @@ class _BnAct(torch.autograd.Function):
             raise ValueError("Expected more than 1 value per channel when training")
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
-        out = new_padded(n, h, y.device, zero_pad=False)
+        # the 16-byte kernels write zeros into the pad columns themselves; the scalar ones (taken when y is
+        # not aligned / padded) touch columns < h only, so the pads are cleared here: consumers read them
+        out = new_padded(n, h, y.device, zero_pad=not is_vec4(y))
         save_mean = torch.empty(h, dtype=torch.float32, device=y.device)
         save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
         _lib.call("hgv_bn_act_fwd", y.data_ptr(), ld_of(y), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
@@ -608,7 +632,7 @@ class _BnAct(torch.autograd.Function):
         n, h = y.shape
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
-        dy = new_padded(n, h, y.device, zero_pad=False)
+        dy = new_padded(n, h, y.device, zero_pad=not (is_vec4(y) and is_vec4(g)))
         need = ctx.needs_input_grad
         # affine gradients: straight into the parameters' .grad buffers when that mode is on
         gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
@@ -630,7 +654,7 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
     _lib.require_cuda(y)
     if not training:
         y = rowmajor(y)
-        out = new_padded(y.size(0), y.size(1), y.device, zero_pad=False)
+        out = new_padded(y.size(0), y.size(1), y.device, zero_pad=not is_vec4(y))
         _lib.call("hgv_bn_act_eval", y.data_ptr(), ld_of(y), y.size(0), y.size(1), int(relu), _lib.ptr(bn.weight),
                   _lib.ptr(bn.bias), float(bn.eps), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                   out.data_ptr(), ld_of(out), _lib.stream())

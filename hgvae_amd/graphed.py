@@ -49,8 +49,21 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for _ in range(warmup):        # allocates workspaces, packs, optimizer state outside the capture
-                self._body(step_optimizer=True, reduce=True)
+            # Warm-up allocates workspaces and weight images outside the capture.  It must not train:
+            # parameters, optimizer state and BatchNorm buffers are as before it when the capture starts.
+            from .optim import FlatAdam
+            lazy_state = not isinstance(optimizer, FlatAdam)    # torch optimizers create their state in step()
+            keep = [(t, t.clone()) for t in list(model.buffers()) + (list(model.parameters()) if lazy_state else [])]
+            for _ in range(warmup):
+                self._body(step_optimizer=lazy_state, reduce=True)
+            with torch.no_grad():
+                for t, saved in keep:
+                    t.copy_(saved)
+                if lazy_state:      # the state tensors now exist; put them back to "no step taken"
+                    for st in optimizer.state.values():
+                        for v in st.values():
+                            if isinstance(v, torch.Tensor):
+                                v.zero_()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         with torch.cuda.graph(self.graph, stream=side):

@@ -75,7 +75,8 @@ class NoiseTape:
         return self._pop(shape, device).to(torch.float32).contiguous(), 0, 0, None
 
 
-_default = PhiloxNoise(seed=0x5EED)
+DEFAULT_SEED = 0x5EED
+_default = PhiloxNoise(seed=DEFAULT_SEED)
 _stack: list = []
 
 

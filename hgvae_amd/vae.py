@@ -9,6 +9,7 @@ statistics: the arithmetic of each level runs in fused HIP kernels
 """
 from __future__ import annotations
 
+import contextlib
 import weakref
 from typing import Optional
 
@@ -99,23 +100,34 @@ class SkipconVAE(_VAEBase):
         self.decoder3 = nn.Sequential(nn.Linear(2 * h, h), nn.Dropout(p), nn.BatchNorm1d(h), nn.Linear(h, in_channels))
         self._conv1_memo = None
 
-    def _conv1(self, x, g):
-        """First convolution, computed once for the two encode passes of a step.
+    @contextlib.contextmanager
+    def share_first_conv(self):
+        """Inside this context the first convolution is evaluated once for a pair of encode passes.
 
-        The reference encodes every batch twice (forward, then ``model.encode`` again for the KL
+        The reference encodes every batch twice per step (forward, then ``model.encode`` again for the KL
         term, gvae/gvae_skipcon.py:166-171).  Nothing stochastic precedes the first SAGEConv, so its
         output is the same tensor in both passes: the second pass reuses it (and the autograd node,
-        so the convolution is also differentiated once, on the summed gradient).  The memo is
-        consumed by the second call and is ignored if the input, graph, weights or grad mode changed.
+        so the convolution is also differentiated once, on the summed gradient).  The sharing is
+        scoped to this context (one loss evaluation, no parameter update inside) and whatever is
+        still pending is dropped on exit; outside it every call computes the convolution.
         """
+        prev, self._conv1_memo = self._conv1_memo, []
+        try:
+            yield
+        finally:
+            self._conv1_memo = prev
+
+    def _conv1(self, x, g):
         conv = self.encoder1[0]
-        key = (x._version, x.data_ptr(), tuple(p._version for p in conv.parameters()), torch.is_grad_enabled())
         memo = self._conv1_memo
-        if memo is not None and memo[0] is x and memo[1] is g and memo[2] == key:
-            self._conv1_memo = None
-            return memo[3]
+        if memo is None:
+            return conv(x, g)
+        if memo and memo[0] is x and memo[1] is g and memo[2] == torch.is_grad_enabled():
+            y = memo[3]
+            memo.clear()
+            return y
         y, y_again = Fn.fork(conv(x, g))
-        self._conv1_memo = (x, g, key, y_again)
+        memo[:] = [x, g, torch.is_grad_enabled(), y_again]
         return y
 
     def _make_level2(self, h, p):
@@ -360,8 +372,10 @@ def train_vae(model, loader, optimizer, lambda_kl=1.0):
 
 def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     """Loss of one reference train step (no backward)."""
-    out = model(x, edge_index, batch)
-    enc = model.encode(x, edge_index)
+    share = getattr(model, "share_first_conv", None)
+    with share() if share is not None else contextlib.nullcontext():
+        out = model(x, edge_index, batch)
+        enc = model.encode(x, edge_index)
     mean, log_std = enc[-2], enc[-1]
     recon_loss = Fn.mse_loss(out[0], padded_input(x))
     kl_loss = model.kl_divergence(mean, log_std)
