@@ -1,67 +1,126 @@
 #!/usr/bin/env python3
-"""GVAE train-step benchmark (graphs/s, edge-messages/s, aggregation HBM roofline).
+"""GVAE train-step benchmark (graphs/s, edge-messages/s, HBM roofline of the aggregation, MFMA rate of the projections).
 
-  python bench.py --gpus N --steps K --warmup W [--workload protein256|large|chig32]
+  python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
 One "step" is the reference's train_vae body for one mini-batch (gvae/gvae_skipcon.py:163-185):
 forward, second encode, mse + kl, backward, gradient all-reduce (N > 1), Adam step.
-Default workload: the headline configuration "synthetic protein-like graphs (~5k nodes, ~60k edges each),
-batch 256 over 8 GPUs" - each rank holds its 32-graph shard (weak scaling), model
-VAE(105, 138, 28) of gvae_skipcon.  Inputs are resident in HBM before the timed region.
 
-Rank 0 prints ONE JSON line.  The CPU baseline (the oracle = reference-equivalent PyG operator
-sequence restated in torch, timed on this host's cores) runs on rank 0 at N=1 only.
+Workloads (model in brackets):
+  protein256   synthetic protein-like graphs (~5k nodes, ~60k directed edges each), GLOBAL batch 256 split evenly
+               over the ranks [gvae_skipcon VAE(105,138,28)] - the default; strong scaling
+  protein32    the same graphs, 32 per rank (the per-GPU shard of the 8-GPU job; weak scaling)
+  large        one graph per rank: 100k nodes, 2M edges, 128-d features [VAE(128,128,28)]; weak scaling
+  chig32       32 chignolin-sized path graphs (138 nodes, 60 features) per rank [VAE(60,138,28)]
+  attention    the chig32 graphs [gvae_skipcon_attention VAE(60,256,28,heads=1)]
+  attention32  the protein32 graphs [gvae_skipcon_attention VAE(105,256,28,heads=1)]
+  pool         8 path graphs of the bundled graphs_2 sizes (454 ... 15200 nodes, 6 features) per rank
+               [vae_with_pool VAE(6,138,28), SAGPooling with the GraphConv scorer in forward]
+  custom_pool  the same graphs [vae_custom_pool VAE(6,138,28), GCNConv-scored pooling, loss re-decodes, beta 0.5]
+
+With N > 1 and no torch.distributed environment the script starts N worker processes itself
+(python -m torch.distributed.run) before it touches the GPU; under torchrun it is a worker.
+Rank 0 prints ONE JSON line.  Inputs and CSR are resident in HBM before the timed region.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+L2_GATHER_GBS = 17800.0        # row gather served by an XCD's L2: 16.8-18.8 TB/s measured chip-wide
+BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an fp32-accurate product costs six bf16 products
+FP32_MFMA_TFLOPS = 157.0
+
+WORKLOADS = {
+    "protein256": ("synthetic protein-like graphs (~5k nodes, ~60k directed edges each), global batch 256 split evenly "
+                   "over the GPUs, gvae_skipcon VAE(105,138,28)", "strong"),
+    "protein32": ("synthetic protein-like graphs (~5k nodes, ~60k directed edges each), 32 graphs per GPU "
+                  "(the per-GPU shard of batch 256 on 8 GPUs), gvae_skipcon VAE(105,138,28)", "weak"),
+    "large": ("one synthetic graph per GPU: 100k nodes, 2M edges, 128-d features, gvae_skipcon VAE(128,128,28)", "weak"),
+    "chig32": ("32 chignolin-sized path graphs (138 nodes, 60 features) per GPU, gvae_skipcon VAE(60,138,28)", "weak"),
+    "attention": ("32 chignolin-sized path graphs per GPU, gvae_skipcon_attention VAE(60,256,28,heads=1)", "weak"),
+    "attention32": ("32 synthetic protein-like graphs per GPU, gvae_skipcon_attention VAE(105,256,28,heads=1)", "weak"),
+    "pool": ("8 path graphs of the bundled graphs_2 sizes (454-15200 nodes, 6 features) per GPU, vae_with_pool "
+             "VAE(6,138,28) with SAGPooling(GraphConv) in forward", "weak"),
+    "custom_pool": ("8 path graphs of the bundled graphs_2 sizes per GPU, vae_custom_pool VAE(6,138,28), "
+                    "GCNConv-scored pooling, re-decoded loss, beta 0.5", "weak"),
+}
+GRAPHS2_SIZES = [454, 2627, 4697, 11213, 11455, 11940, 13239, 15200]
 
 
-def agg_bytes(n, f, e):
-    """Algorithmic bytes of one aggregation launch: one neighbour row per message, the output, col, rowptr."""
+def agg_gather_bytes(n, f, e):
+    """Bytes one aggregation launch consumes when every message reads its neighbour row: 4FE + output + col + rowptr."""
     return 4 * f * e + 4 * f * n + 4 * e + 4 * (n + 1)
 
 
-def measured_traffic(workload, f):
-    """HBM bytes per aggregation launch from the committed rocprofv3 PMC summary (FETCH_SIZE x2 + WRITE_SIZE,
-    calibrated on a copy of known size); None when no summary exists for this workload / width."""
-    path = os.path.join(ROOT, "profiles", f"agg_pmc_{workload}.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    return d["agg_fwd"]["hbm_bytes_per_launch"] if d.get("F") == f else None
+def agg_compulsory_bytes(n, f, e, ld=None):
+    """Every distinct byte of an aggregation launch once: the feature table read, the output written, col, rowptr."""
+    ld = ld or (f + 3) // 4 * 4
+    return 2 * 4 * ld * n + 4 * e + 4 * (n + 1)
 
 
-def build_workload(name, rank, device):
+def load_pmc(workload, graphs):
+    """Counter summary of this workload written by tools/pmc_bench.sh (separate rocprofv3 --pmc passes); None if absent."""
+    for name in (f"pmc_{workload}_b{graphs}.json", f"pmc_{workload}.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+    return None
+
+
+def build_workload(name, rank, world, device):
+    """(batch, model kind, model dims) for this rank."""
     from hgvae_amd import synthetic
-    if name == "protein256":
-        batch = synthetic.protein_like_batch(32, seed=1000 + rank, device=device)
-        dims = (105, 138, 28)
-    elif name == "large":
-        batch = synthetic.local_random_graph(100_000, 20, 128, seed=1000 + rank, device=device)
-        dims = (128, 128, 28)
-    elif name == "chig32":
-        batch = synthetic.path_graph_batch([138] * 32, 60, seed=1000 + rank, device=device)
-        dims = (60, 138, 28)
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    return batch, dims
+    seed = 1000 + rank
+    if name in ("protein256", "protein32", "attention32"):
+        from hgvae_amd.distributed import shard_range
+        graphs = len(shard_range(256, rank, world)) if name == "protein256" else 32
+        batch = synthetic.protein_like_batch(graphs, seed=seed, device=device)
+        return (batch, "attention", (105, 256, 28)) if name == "attention32" else (batch, "skipcon", (105, 138, 28))
+    if name == "large":
+        return synthetic.local_random_graph(100_000, 20, 128, seed=seed, device=device), "skipcon", (128, 128, 28)
+    if name in ("chig32", "attention"):
+        batch = synthetic.path_graph_batch([138] * 32, 60, seed=seed, device=device)
+        return (batch, "skipcon", (60, 138, 28)) if name == "chig32" else (batch, "attention", (60, 256, 28))
+    if name in ("pool", "custom_pool"):
+        return synthetic.path_graph_batch(GRAPHS2_SIZES, 6, seed=seed, device=device), name, (6, 138, 28)
+    raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(batch, dims, sample_graphs, lambda_kl=1.0):
-    """Time the oracle's train step (forward, second encode, loss, backward, Adam) on host cores."""
+def make_model(kind, dims):
+    from hgvae_amd import vae
+    if kind == "skipcon":
+        return vae.SkipconVAE(*dims), vae.train_step_loss
+    if kind == "attention":
+        return vae.SkipconAttentionVAE(*dims, heads=1), vae.train_step_loss
+    if kind == "pool":
+        return vae.PoolVAE(*dims), vae.train_step_loss
+    model = vae.CustomPoolVAE(*dims)
+    return model, (lambda m, x, ei, b, _lam: vae.custom_pool_step_loss(m, x, ei, b))
+
+
+def reference_aggregations(kind):
+    """Aggregations (of E messages each; GAT ones of E + N) one reference train step performs: (sage, gat)."""
+    if kind == "skipcon":
+        return 14, 0        # 4 convs x 2 passes forward, convs 2-4 x 2 passes backward
+    if kind == "attention":
+        return 10, 4        # (3 SAGE + 1 GAT) x 2 forward, (2 SAGE + 1 GAT) x 2 backward
+    # pool variants: 3 convs x 2 passes forward + convs 2-3 x 2 backward + the scorer's aggregation (forward only)
+    return 11, 0
+
+
+def cpu_baseline(batch, kind, dims, sample_graphs, budget_s=10.0):
+    """The oracle's train step (forward, second encode, loss, backward, Adam) timed on this host's cores."""
+    import torch
     from hgvae_amd.data import Batch, Data
     from oracle import models as OM
     ptr = batch.ptr.cpu().tolist()
@@ -74,14 +133,19 @@ def cpu_baseline(batch, dims, sample_graphs, lambda_kl=1.0):
     sub = Batch.from_data_list(items)
     threads = torch.get_num_threads()
     torch.manual_seed(0)
-    model = OM.SkipconVAE(*dims)
+    model, loss_fn = {
+        "skipcon": (OM.SkipconVAE, lambda m: OM.skipcon_loss(m, sub.x, sub.edge_index, sub.batch, 1.0)[0]),
+        "attention": (OM.SkipconAttentionVAE, lambda m: OM.skipcon_loss(m, sub.x, sub.edge_index, sub.batch, 1.0)[0]),
+        "pool": (OM.PoolVAE, lambda m: OM.pool_loss(m, sub.x, sub.edge_index, sub.batch, 1.0)[0]),
+        "custom_pool": (OM.CustomPoolVAE, lambda m: OM.custom_pool_loss(m, sub.x, sub.edge_index, sub.batch)[0]),
+    }[kind]
+    model = model(*dims)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     model.train()
 
     def step():
         opt.zero_grad()
-        loss = OM.skipcon_loss(model, sub.x, sub.edge_index, sub.batch, lambda_kl)[0]
-        loss.backward()
+        loss_fn(model).backward()
         opt.step()
 
     step()  # warm-up
@@ -90,13 +154,26 @@ def cpu_baseline(batch, dims, sample_graphs, lambda_kl=1.0):
         step()
         n += 1
         dt = time.perf_counter() - t0
-        if dt > 10.0 or n >= 10:
+        if dt > budget_s or n >= 10:
             break
+    sage, gat = reference_aggregations(kind)
+    e, nn_ = sub.edge_index.size(1), sub.x.size(0)
     return {"value": len(items) * n / dt, "unit": "graphs/s", "cores": threads, "kind": "port",
             "sample": f"{len(items)} of the {len(ptr) - 1} graphs of rank 0's batch "
-                      f"({sub.x.size(0)} nodes, {sub.edge_index.size(1)} edges), {n} train steps after 1 warm-up, "
+                      f"({nn_} nodes, {e} edges), {n} train steps after 1 warm-up, "
                       f"{dt:.1f} s; torch CPU restatement of the PyG operator sequence",
-            "edge_messages_per_s": 14 * sub.edge_index.size(1) * n / dt}
+            "edge_messages_per_s": (sage * e + gat * (e + nn_)) * n / dt}
+
+
+def spawn_workers(args):
+    """Start one worker per GPU with torch.distributed.run and pass its output through.  Runs before anything in
+    this process has touched the GPU; this process only waits."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -104,37 +181,41 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="protein256")
+    ap.add_argument("--workload", default="protein256", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one captured HIP graph (per-launch event timing is then taken "
-                         "from a short eager pass after the timed region)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph")
     ap.add_argument("--cpu-sample-graphs", type=int, default=8)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of hgvae_amd.optim.FlatAdam")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_workers(args))
+
+    import torch
     import torch.distributed as dist
     import hgvae_amd
     from hgvae_amd import functional as Fn
-    from hgvae_amd.distributed import FlatGradBucket, barrier, init_from_env
+    from hgvae_amd.distributed import FlatGradBucket, all_reduce_any, barrier, init_from_env
     from hgvae_amd.graph import graph_of
-    from hgvae_amd.vae import SkipconVAE, train_step_loss
 
     rank, world, local_rank = init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    backend = dist.get_backend() if world > 1 else None
 
     def note(msg):
         print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     note(f"building workload {args.workload} on cuda:{local_rank}")
-    batch, dims = build_workload(args.workload, rank, device)
+    batch, kind, dims = build_workload(args.workload, rank, world, device)
     n_nodes, n_edges, n_graphs = batch.x.size(0), batch.edge_index.size(1), batch.num_graphs
-    torch.manual_seed(0)
-    hgvae_amd.manual_seed(1234 + rank)
-    model = SkipconVAE(*dims).to(device).train()
+    torch.manual_seed(0)                  # identical initial weights on every rank
+    noise_seed = 1234 + rank              # per-rank dropout / eps streams
+    hgvae_amd.manual_seed(noise_seed)
+    model, loss_fn = make_model(kind, dims)
+    model = model.to(device).train()
     if args.torch_adam:
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=args.graph)
         bucket = FlatGradBucket(model.parameters())
@@ -147,20 +228,21 @@ def main():
 
     def step():
         bucket.zero()
-        loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+        loss = loss_fn(model, batch.x, batch.edge_index, batch.batch, 1.0)
         with Fn.direct_weight_grads():      # weight gradients are added into the bucket views by the kernels
             loss.backward()
         bucket.all_reduce_mean()
         opt.step()
         return loss
 
-    note("workload and CSR ready; warm-up")
-    probe = Fn.LaunchProbe()
+    eager_step = step
     if args.graph:
+        if kind in ("pool", "custom_pool"):
+            raise SystemExit("the pooling variants size their outputs on the host and cannot be captured")
         from hgvae_amd.graphed import GraphedTrainStep
-        eager_step = step
         step = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, bucket=bucket,
-                                seed=1234 + rank, warmup=max(args.warmup, 1))
+                                seed=noise_seed, warmup=max(args.warmup, 1))
+    note("workload and CSR ready; warm-up")
     for _ in range(args.warmup):
         step()
     # A generation-2 pass of Python's collector walks every object torch has created (~40 ms here) and,
@@ -169,11 +251,10 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    note("timed region")
-    if not args.graph:
-        Fn.set_probe(probe)
     torch.cuda.synchronize()
+    note("warm-up done; barrier")
     barrier()
+    note("timed region")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -181,71 +262,131 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if args.graph:   # kernels inside a replayed graph cannot be bracketed by events: time them eagerly now
-        Fn.set_probe(probe)
-        for _ in range(3):
-            eager_step()
-        torch.cuda.synchronize()
-    Fn.set_probe(None)
+    note(f"timed region done: {elapsed * 1e3 / args.steps:.3f} ms/step")
 
-    stats = torch.tensor([elapsed, float(n_graphs), float(n_edges), float(n_nodes)], dtype=torch.float64, device=device)
+    # per-launch durations of the aggregation and projection kernels: HIP events on the launching stream around
+    # every launch, in a pass of its own after the timed region (the events cost ~4 us per launch)
+    probe, probe_steps = Fn.LaunchProbe(), 3
+    if rank == 0:
+        Fn.set_probe(probe)
+        for _ in range(probe_steps):
+            bucket.zero()
+            with Fn.direct_weight_grads():
+                loss_fn(model, batch.x, batch.edge_index, batch.batch, 1.0).backward()
+        torch.cuda.synchronize()
+        Fn.set_probe(None)
+
+    stats = torch.tensor([float(n_graphs), float(n_edges), float(n_nodes)], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        elapsed = mx[0].item()
-    tot_graphs, tot_edges, tot_nodes = stats[1].item(), stats[2].item(), stats[3].item()
+        all_reduce_any(tmax, dist.ReduceOp.MAX)
+        all_reduce_any(stats, dist.ReduceOp.SUM)
+        elapsed = tmax[0].item()
+    tot_graphs, tot_edges, tot_nodes = stats.tolist()
 
     if rank == 0:
-        # roofline of the dominant kernel k_aggregate<4,false,*> (unweighted aggregation, every width it ran at):
-        # sum of algorithmic bytes / sum of launch durations, so that avg_launch_us is directly comparable with
-        # the rocprofv3 --kernel-trace --stats average for that kernel name
-        recs = probe.durations_ms()
+        step_s = elapsed / args.steps
+        pmc = load_pmc(args.workload, n_graphs) if world == 1 else None
         h = dims[1]
-        dom = [(n, f, e, ms) for (n, f, e, w, ms) in recs if not w]
-        wtd = [(n, f, e, ms) for (n, f, e, w, ms) in recs if w]
+        recs = probe.durations_ms()
+        agg = [(sh, ms) for (k, sh, ms) in recs if k == "agg"]
+        aggw = [(sh, ms) for (k, sh, ms) in recs if k == "agg_w"]
+        at_h = [(sh, ms) for (sh, ms) in agg if sh[1] == h and sh[0] == n_nodes] or agg
+
+        def rate(items, model_fn):
+            ms = sum(m for (_, m) in items)
+            return sum(model_fn(*sh) for (sh, _) in items) / (ms * 1e-3) / 1e9 if ms > 0 else None
+
         roof = None
-        if dom:
-            tot_ms = sum(ms for (*_, ms) in dom)
-            tot_b = sum(agg_bytes(n, f, e) for (n, f, e, ms) in dom)
-            achieved = tot_b / (tot_ms * 1e-3) / 1e9
-            at_h = [ms for (n, f, e, ms) in dom if f == h]
-            roof = {"bound": "hbm", "kernel": "k_aggregate<4,false,*>", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(args.workload, h),
-                    "avg_launch_us": round(tot_ms / len(dom) * 1e3, 2), "launches": len(dom),
-                    "algorithmic_bytes_per_launch": round(tot_b / len(dom)),
-                    "widths": sorted({f for (n, f, e, ms) in dom}),
-                    "at_hidden_width": {"F": h, "avg_launch_us": round(sum(at_h) / len(at_h) * 1e3, 2) if at_h else None,
-                                        "algorithmic_bytes": agg_bytes(n_nodes, h, n_edges),
-                                        "traffic_note": "traffic is the PMC-measured HBM bytes of one launch at this width"},
-                    "weighted_kernel": {"kernel": "k_aggregate<4,true,*>", "launches": len(wtd),
-                                        "avg_launch_us": round(sum(ms for (*_, ms) in wtd) / len(wtd) * 1e3, 2) if wtd else None,
-                                        "achieved": round(sum(agg_bytes(n, f, e) + 4 * e for (n, f, e, ms) in wtd)
-                                                          / (sum(ms for (*_, ms) in wtd) * 1e-3) / 1e9, 1) if wtd else None}}
+        if at_h:
+            us = sum(ms for (_, ms) in at_h) / len(at_h) * 1e3
+            (n_r, f_r, e_r) = at_h[0][0]
+            comp = agg_compulsory_bytes(n_r, f_r, e_r)
+            traffic = None
+            if pmc and pmc.get("aggregation", {}).get("F") == f_r:
+                traffic = pmc["aggregation"]["hbm_bytes_per_launch"]
+            hbm_bytes = traffic if traffic is not None else comp
+            achieved = hbm_bytes / (us * 1e-6) / 1e9
+            gathered = agg_gather_bytes(n_r, f_r, e_r) / (us * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": f"k_aggregate<4,false,*> forward aggregation at F={f_r}",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "bytes": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch" if traffic is not None
+                             else "compulsory bytes (every distinct byte once); no counter summary for this workload",
+                    "avg_launch_us": round(us, 2), "launches_timed": len(at_h),
+                    "compulsory_bytes_per_launch": comp,
+                    "gather_bytes_per_launch": agg_gather_bytes(n_r, f_r, e_r),
+                    "gathered_GBps": round(gathered, 1),
+                    "cache_gather_frac": round(gathered / L2_GATHER_GBS, 4),
+                    "note": "gathered_GBps = one neighbour row per message (4FE + 4FN + 4E + 4(N+1)) / time; the re-reads "
+                            "are served by L2 / Infinity Cache, so it is priced against the L2 row-gather rate "
+                            f"({L2_GATHER_GBS:.0f} GB/s), not against HBM",
+                    "all_unweighted": {"launches_per_step": len(agg) // probe_steps,
+                                       "avg_launch_us": round(sum(ms for (_, ms) in agg) / len(agg) * 1e3, 2),
+                                       "gathered_GBps": round(rate(agg, agg_gather_bytes), 1),
+                                       "compulsory_GBps": round(rate(agg, agg_compulsory_bytes), 1),
+                                       "widths": sorted({sh[1] for (sh, _) in agg})}}
+            if aggw:
+                roof["weighted"] = {"kernel": "k_aggregate<4,true,*> (transposed / attention-weighted)",
+                                    "launches_per_step": len(aggw) // probe_steps,
+                                    "avg_launch_us": round(sum(ms for (_, ms) in aggw) / len(aggw) * 1e3, 2),
+                                    "gathered_GBps": round(rate(aggw, lambda n, f, e: agg_gather_bytes(n, f, e) + 4 * e), 1),
+                                    "compulsory_GBps": round(rate(aggw, lambda n, f, e: agg_compulsory_bytes(n, f, e) + 4 * e), 1)}
+            proj = {}
+            for kname, label in (("nt", "C[M,N] = A[M,K] W^T (forward and grad-input products)"),
+                                 ("tn", "GW[N,K] = G^T A (weight gradients, reduction included)")):
+                items = [(sh, ms) for (k, sh, ms) in recs if k == kname]
+                if not items:
+                    continue
+                ms = sum(m for (_, m) in items)
+                flops = sum(2.0 * a * b * c for ((a, b, c), _) in items)
+                operand = sum(4.0 * (a * b + a * c) for ((a, b, c), _) in items)     # both row-count-sized operands once
+                ent = {"what": label, "launches_per_step": len(items) // probe_steps,
+                       "ms_per_step": round(ms / probe_steps, 3),
+                       "tflops_fp32_equiv": round(flops / (ms * 1e-3) / 1e12, 1),
+                       "frac_of_bf16x6_peak": round(flops / (ms * 1e-3) / 1e12 / (BF16_DENSE_TFLOPS / 6), 4),
+                       "operand_GBps": round(operand / (ms * 1e-3) / 1e9, 1),
+                       "operand_frac_of_hbm_peak": round(operand / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                if pmc and kname in pmc.get("projections", {}):
+                    ent.update(pmc["projections"][kname])
+                proj[kname] = ent
+            roof["projections"] = proj
+            if pmc and "step" in pmc:
+                sb = pmc["step"]["hbm_bytes"]
+                roof["step_hbm_bytes"] = sb
+                roof["step_hbm_frac"] = round(sb / step_s / 1e9 / HBM_PEAK_GBS, 4)
+            else:
+                roof["step_hbm_bytes"] = roof["step_hbm_frac"] = None
+        executed = sum(sh[2] for (k, sh, _) in recs if k in ("agg", "agg_w")) / probe_steps
+        sage, gat = reference_aggregations(kind)
+        ref_msgs = sage * tot_edges + gat * (tot_edges + tot_nodes)
         out = {
-            "metric": "GVAE train graphs/sec", "value": round(tot_graphs * args.steps / elapsed, 2),
+            "metric": "GVAE train graphs/sec", "value": round(tot_graphs / step_s, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": WORKLOADS[args.workload][1],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"protein256": "synthetic protein-like graphs (~5k nodes, ~60k directed edges each), "
-                                                  "32 graphs per GPU (global batch 256 at 8 GPUs), gvae_skipcon VAE(105,138,28)",
-                                    "large": "one synthetic graph per GPU: 100k nodes, 2M edges, 128-d features, VAE(128,128,28)",
-                                    "chig32": "32 chignolin-sized path graphs (138 nodes) per GPU, VAE(60,138,28)"}[args.workload],
+            "config": {"workload": WORKLOADS[args.workload][0], "name": args.workload,
                        "graphs_per_gpu": n_graphs, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
-                       "parallelism": f"dp{world}",
+                       "global_batch": int(tot_graphs), "parallelism": f"dp{world}",
+                       "collective": None if world == 1 else f"one all-reduce of the flat fp32 gradient bucket "
+                                                             f"({bucket.flat.numel()} floats) per step, backend {backend}",
+                       "batchnorm": "statistics and running buffers are rank-local (nodes of the local shard); "
+                                    "parameters stay identical through the averaged gradients",
+                       "seeds": "weights torch.manual_seed(0) on every rank; graphs 1000 + rank; dropout / eps Philox "
+                                "streams 1234 + rank",
                        "optimizer": "Adam lr=1e-3 (torch fused)" if args.torch_adam else "Adam lr=1e-3 (FlatAdam, torch arithmetic)",
-                       "launch": "hip graph replay" if args.graph else "eager",
-                       "note": "edge_messages_per_s counts the reference's 14 aggregations x E per step; the first "
-                               "convolution (no stochastic layer precedes it) is evaluated once for both encode passes"},
-            "edge_messages_per_s": round(14 * tot_edges * args.steps / elapsed, 1),
+                       "launch": "hip graph replay" if args.graph else "eager"},
+            "edge_messages_per_s": round(ref_msgs / step_s, 1),
+            "edge_messages_executed_per_s": round(executed * (tot_edges / n_edges) / step_s, 1),
+            "edge_messages_note": f"edge_messages_per_s counts the reference's aggregations per step ({sage} x E"
+                                  + (f" + {gat} x (E + N)" if gat else "") + "); executed = edges walked by the aggregation "
+                                  "launches of one step here (the first convolution is evaluated once for both encode passes)",
             "loss": round(float(loss.item()), 6),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            if args.cpu_sample_graphs > 0:
-                out["cpu_baseline"] = cpu_baseline(batch, dims, args.cpu_sample_graphs)
+        if world == 1 and not args.no_cpu_baseline and args.cpu_sample_graphs > 0:
+            out["cpu_baseline"] = cpu_baseline(batch, kind, dims, args.cpu_sample_graphs)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -25,11 +25,14 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
+        n_dev = torch.cuda.device_count()
         if backend is None:
-            # HGVAE_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box)
-            backend = os.environ.get("HGVAE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        if torch.cuda.is_available():
-            local_rank = local_rank % torch.cuda.device_count()
+            # RCCL needs one GPU per rank.  With fewer GPUs than ranks (rehearsal on a 1-GPU box) the ranks
+            # share the devices and the collectives run over gloo on host copies (HGVAE_DIST_BACKEND overrides).
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+            backend = os.environ.get("HGVAE_DIST_BACKEND") or ("nccl" if n_dev >= local_world else "gloo")
+        if n_dev > 0:
+            local_rank = local_rank % n_dev
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         # per-rank dropout / eps streams: the Philox counters are (row, chunk, offset), so ranks sharing one
@@ -95,14 +98,28 @@ class FlatGradBucket:
         """Sum the bucket over ranks and divide by the world size (no-op for one rank)."""
         self.gather()
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_any(self.flat, dist.ReduceOp.SUM, self.group)
             self.flat.div_(self.world)
+
+
+def all_reduce_any(t: torch.Tensor, op=dist.ReduceOp.SUM, group=None) -> torch.Tensor:
+    """In-place all-reduce of ``t``.  Device tensors go straight to RCCL; under the gloo backend (CPU tests,
+    several ranks sharing one GPU) they are reduced through a host copy, because gloo's own handling of device
+    tensors is not available in every build and never returns when it is missing."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
 
 
 def all_reduce_scalar_mean(t: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = t.clone()
-        dist.all_reduce(t, group=group)
+        t = all_reduce_any(t.clone(), group=group)
         t /= dist.get_world_size(group)
     return t
 
