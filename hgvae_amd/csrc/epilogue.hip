@@ -19,6 +19,7 @@
 // keep probability quantised to 1/65536): the integer multiplies of the generator, not memory,
 // bounded these kernels when every 4 elements paid for a call of their own.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -484,6 +485,26 @@ extern "C" size_t hgv_bn_act_ws(int64_t N, int H) {
     return hgv_align256(2048 * 2 * Hp * sizeof(float)) + hgv_align256(2 * Hp * sizeof(float));
 }
 
+namespace {
+// Launch sequence of the training-mode forward; partial = [nblocks <= 1024][2][Hp] floats of scratch.
+int bn_act_fwd_launch(const EpArgs& a, int nb, const float* gamma, const float* beta, float eps, float* running_mean,
+                      float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
+                      float* out, int64_t ldo, float* partial, hipStream_t stream) {
+    const int Hp = a.CH * 4;
+    const bool vec = vec4_ok(a.y, a.ldy, Hp) && vec4_ok(out, ldo, Hp);
+    if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
+    else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((a.H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked);
+    NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
+    if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
+    else hipLaunchKernelGGL(k_ep_apply<false>, dim3(nb), dim3(256), 0, stream, a, n);
+    HGV_CHECK_LAUNCH("bn_act_fwd");
+    return HGV_OK;
+}
+
+}  // namespace
+
 // Training-mode forward.  num_batches_tracked (nullable device int64) is incremented.  mask: explicit keep mask [N,H] (uint8, contiguous) or null; with
 // p > 0 and no mask the keep decisions come from Philox4x32 keyed by (seed, offset, row, chunk pair),
 // 16 random bits per element, and the backward pass regenerates them from the same (seed, offset).
@@ -498,18 +519,61 @@ extern "C" int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(out && ldo >= H && save_mean && save_rstd && ws, HGV_EINVAL, "bn_act_fwd: null/short buffer");
     HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_fwd: workspace too small or misaligned");
-    const int Hp = a.CH * 4;
-    float* partial = (float*)ws;
-    const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(out, ldo, Hp);
-    if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
-    else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, N,
-                       H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked);
-    NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
-    if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
-    else hipLaunchKernelGGL(k_ep_apply<false>, dim3(nb), dim3(256), 0, stream, a, n);
-    HGV_CHECK_LAUNCH("bn_act_fwd");
+    return bn_act_fwd_launch(a, nb, gamma, beta, eps, running_mean, running_var, momentum, num_batches_tracked, save_mean,
+                             save_rstd, out, ldo, (float*)ws, stream);
+}
+
+// ---- the same forward for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid
+// hipMalloc): the partial column statistics live in a device array of this library instead of a caller workspace.
+// Every GPU the library runs on holds its own copy of the array (2.25 MiB) until the process ends.
+#define HGV_BN_STATIC_MAX_H 288
+#define HGV_BN_STATIC_MAX_BLOCKS 1024      // make_args never uses more row ranges than this
+static __device__ __align__(256) float scratch[(size_t)HGV_BN_STATIC_MAX_BLOCKS * 2 * HGV_BN_STATIC_MAX_H];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of this GPU's copy of `scratch`, resolved once per device with that device current.  The array's
+// name is only a host-side handle: kernels must be given this address, never the name.
+int scratch_of_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    HGV_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, HGV_ELAUNCH, "bn_act_fwd_static: hipGetDevice failed (%s)",
+                hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        HGV_REQUIRE(e == hipSuccess && p != nullptr, HGV_ELAUNCH, "bn_act_fwd_static: hipGetSymbolAddress failed on device %d (%s)",
+                    dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
     return HGV_OK;
+}
+}  // namespace
+
+extern "C" int hgv_bn_act_fwd_static(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
+                                     uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma,
+                                     const float* beta, float eps, float* running_mean, float* running_var,
+                                     float momentum, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
+                                     float* out, int64_t ldo, hipStream_t stream) {
+    HGV_REQUIRE(H <= HGV_BN_STATIC_MAX_H, HGV_EUNSUPPORTED,
+                "bn_act_fwd_static: H=%d exceeds the built-in scratch (H <= %d); use hgv_bn_act_fwd with a workspace", H,
+                HGV_BN_STATIC_MAX_H);
+    EpArgs a; int nb;
+    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(out && ldo >= H && save_mean && save_rstd, HGV_EINVAL, "bn_act_fwd_static: null/short buffer");
+    HGV_REQUIRE(nb <= HGV_BN_STATIC_MAX_BLOCKS, HGV_EUNSUPPORTED, "bn_act_fwd_static: %d row ranges exceed the built-in scratch", nb);
+    float* partial = nullptr;
+    rc = scratch_of_current_device(&partial);
+    if (rc != HGV_OK) return rc;
+    // every row range [0, nb) writes its (mean, M2) pair before the merge kernel reads it: nothing has to start at zero
+    return bn_act_fwd_launch(a, nb, gamma, beta, eps, running_mean, running_var, momentum, num_batches_tracked, save_mean,
+                             save_rstd, out, ldo, partial, stream);
 }
 
 // Eval-mode forward: no dropout, running statistics.

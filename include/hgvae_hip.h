@@ -109,6 +109,18 @@ int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, floa
                    float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
                    float* save_mean, float* save_rstd, float* out, int64_t ldo, void* ws, size_t ws_bytes,
                    hgv_stream_t stream);
+/* hgv_bn_act_fwd without a workspace argument and without any allocation.  No counterpart in the reference: it
+ * exists for callers that cannot allocate device memory around the call (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  The partial column statistics go to a device array inside the library
+ * (2.25 MiB per GPU, held until the process ends) instead of ws; limits: H <= 288 (larger H is rejected with
+ * HGV_EUNSUPPORTED - use hgv_bn_act_fwd), any N.  Same kernels and results as hgv_bn_act_fwd, bit for bit.  All calls
+ * on one GPU share that array: calls that overlap on one GPU (different streams or host threads) race; calls on one
+ * stream are ordered and safe.  The first call on each device resolves the array's address (hipGetSymbolAddress); make
+ * that first call outside a graph capture. */
+int hgv_bn_act_fwd_static(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
+                          uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta,
+                          float eps, float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                          float* save_mean, float* save_rstd, float* out, int64_t ldo, hgv_stream_t stream);
 int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, int relu, const float* gamma, const float* beta,
                     float eps, const float* running_mean, const float* running_var, float* out, int64_t ldo,
                     hgv_stream_t stream);
