@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-step kernel summary from a rocprofv3 kernel trace of bench.py:
-step_profile.py <kernel_trace.csv> <steps_in_trace>  (uses the last full step: kernels between Adam launches)."""
+step_profile.py <kernel_trace.csv> [lines] [sequence file]  (uses the last full step: kernels between Adam launches)."""
 import collections
 import csv
 import re
@@ -33,6 +33,13 @@ def main():
         acc[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     for k, (n, ns) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 30]:
         print(f"{k:52s} x{n:3d}  {ns / 1e3:8.1f} us")
+    if len(sys.argv) > 3:       # the step's launches in order: start offset, duration, gap to the previous kernel's end
+        with open(sys.argv[3], "w") as f:
+            prev = t0
+            for r in step:
+                s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                f.write(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:7.1f} us  gap {(s - prev) / 1e3:6.1f}  {short(r['Kernel_Name'])}\n")
+                prev = e
 
 
 if __name__ == "__main__":
