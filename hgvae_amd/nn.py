@@ -128,23 +128,49 @@ class GATConv(nn.Module):
         return out + self.bias
 
 
+class SelectTopK(nn.Module):
+    """The scalar selector PyG >= 2.4 keeps inside SAGPooling (checkpoint key ``select.weight``, shape [1, 1],
+    U(-1, 1) at init): score = tanh(s * w / ||w||)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(1, 1).uniform_(-1.0, 1.0))
+
+    def forward(self, s: torch.Tensor) -> torch.Tensor:
+        w = self.weight.view(-1)
+        return torch.tanh(s * (w / w.norm(p=2)))
+
+
 class SAGPooling(nn.Module):
     """Self-attention graph pooling (PyG SAGPooling: ratio=0.5, GNN scorer -> tanh -> per-graph top-k).
 
     Returns ``(x[perm] * score[perm], edge_index_cg, edge_attr_cg, batch[perm], perm, score[perm])``.
+
+    PyG <= 2.3 scores nodes with ``tanh(gnn(x))``.  PyG >= 2.4 routes the GNN output through a ``SelectTopK``
+    module with one learnable scalar (``select.weight``): ``tanh(gnn(x) * w / ||w||)``.  ``select_weight=True``
+    builds that variant; loading a checkpoint that holds ``select.weight`` switches to it as well, so
+    ``load_state_dict`` accepts files written by either PyG generation.
     """
 
-    def __init__(self, in_channels: int, ratio: float = 0.5, GNN=GraphConv, **kwargs):
+    def __init__(self, in_channels: int, ratio: float = 0.5, GNN=GraphConv, select_weight: bool = False, **kwargs):
         super().__init__()
         self.in_channels, self.ratio = in_channels, ratio
         self.gnn = GNN(in_channels, 1, **kwargs)
+        self.select = SelectTopK() if select_weight else None
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if prefix + "select.weight" in state_dict and self.select is None:
+            ref = self.gnn.parameters().__next__()
+            self.select = SelectTopK().to(ref.device)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     def forward(self, x, edge_index, edge_attr=None, batch=None):
         n = x.size(0)
         if batch is None:
             batch = torch.zeros(n, dtype=torch.long, device=x.device)
         raw_ei = edge_index.edge_index if isinstance(edge_index, Graph) else edge_index
-        score = torch.tanh(self.gnn(x, edge_index).reshape(-1))
+        s = self.gnn(x, edge_index).reshape(-1)
+        score = torch.tanh(s) if self.select is None else self.select(s)
         perm = Fn.topk_perm(score, self.ratio, batch)
         x_out = Fn.gather_rows(x, perm, score)
         b_out = Fn.gather_i64(batch, perm)

@@ -257,18 +257,36 @@ def filter_adj(edge_index: Tensor, edge_attr: Optional[Tensor], perm: Tensor, nu
     return torch.stack([r[keep], c[keep]], dim=0), ea
 
 
-class SAGPooling(nn.Module):
-    """PyG SAGPooling(in_channels, ratio=0.5, GNN=GraphConv, nonlinearity=tanh)."""
+class SelectTopK(nn.Module):
+    """Scalar selector that PyG >= 2.4 places inside SAGPooling (``select.weight`` [1, 1], U(-1, 1) at init):
+    score = tanh(s * w / ||w||), i.e. the sign of ``w`` decides whether high or low GNN outputs are kept."""
 
-    def __init__(self, in_channels: int, ratio: float = 0.5, GNN=GraphConv):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(1, 1).uniform_(-1.0, 1.0))
+
+    def forward(self, s: Tensor) -> Tensor:
+        score = (s.view(-1, 1) * self.weight).sum(dim=-1)
+        return torch.tanh(score / self.weight.norm(p=2, dim=-1))
+
+
+class SAGPooling(nn.Module):
+    """PyG SAGPooling(in_channels, ratio=0.5, GNN=GraphConv, nonlinearity=tanh).
+
+    ``select_weight=False`` restates PyG <= 2.3 (score = tanh(gnn(x))); ``True`` restates PyG >= 2.4, whose
+    SelectTopK multiplies the GNN output by a learnable scalar before the nonlinearity."""
+
+    def __init__(self, in_channels: int, ratio: float = 0.5, GNN=GraphConv, select_weight: bool = False):
         super().__init__()
         self.ratio = ratio
         self.gnn = GNN(in_channels, 1)
+        self.select = SelectTopK() if select_weight else None
 
     def forward(self, x, edge_index, edge_attr=None, batch=None):
         if batch is None:
             batch = edge_index.new_zeros(x.size(0))
-        score = torch.tanh(self.gnn(x, edge_index).view(-1))
+        s = self.gnn(x, edge_index).view(-1)
+        score = torch.tanh(s) if self.select is None else self.select(s)
         perm = topk(score, self.ratio, batch)
         x_out = x[perm] * score[perm].view(-1, 1)
         b_out = batch[perm]

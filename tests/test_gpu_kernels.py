@@ -417,6 +417,35 @@ def test_sag_pooling_matches_oracle(scorer):
         pytest.fail("top-k order differs from the oracle on a seeded input without ties")
 
 
+def test_sag_pooling_with_select_weight_matches_oracle_and_loads_either_checkpoint():
+    """PyG >= 2.4 checkpoints carry ``select.weight``; the score is tanh(gnn(x) * w / ||w||)."""
+    from hgvae_amd import nn as HN
+    gen = torch.Generator().manual_seed(48)
+    ei, n, batch = path_batch([300, 154, 9])
+    h = 138
+    torch.manual_seed(6)
+    ref = O.SAGPooling(h, GNN=O.GraphConv, select_weight=True)
+    with torch.no_grad():
+        ref.select.weight.fill_(-0.7)
+    mod = HN.SAGPooling(h, GNN=HN.GraphConv)              # built the PyG <= 2.3 way ...
+    assert "select.weight" not in mod.state_dict()
+    mod.load_state_dict(ref.state_dict())                 # ... and switched by the checkpoint's key
+    assert float(mod.select.weight.detach()) == pytest.approx(-0.7)
+    mod = mod.to(dev())
+    x = torch.randn(n, h, generator=gen)
+    rx, rei, _, rb, rperm, rs = ref(x, ei, None, batch)
+    ox, oei, _, ob, operm, os_ = mod(x.to(dev()), ei.to(dev()), None, batch.to(dev()))
+    assert torch.equal(operm.cpu(), rperm)
+    close(ox, rx, FWD_RTOL)
+    close(os_, rs, FWD_RTOL)
+    assert torch.equal(oei.cpu(), rei) and torch.equal(ob.cpu(), rb)
+    # the older layout still loads into a model built with the selector only if the key is present
+    old = O.SAGPooling(h, GNN=O.GraphConv)
+    HN.SAGPooling(h, GNN=HN.GraphConv).load_state_dict(old.state_dict())
+    with pytest.raises(RuntimeError):
+        HN.SAGPooling(h, GNN=HN.GraphConv, select_weight=True).load_state_dict(old.state_dict())
+
+
 # ------------------------------------------------------------------ fp32 MFMA projections
 GEMM_SHAPES = [  # (M, K1, K2, N)
     (1, 6, None, 1), (127, 28, None, 138), (129, 138, 138, 138), (1000, 105, 105, 138), (777, 138, 138, 56),

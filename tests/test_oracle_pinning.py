@@ -72,6 +72,25 @@ def test_topk_and_filter_adj_known_answers():
     assert out.tolist() == [[0, 1, 2], [1, 2, 0]] and ea.view(-1).tolist() == [1.0, 2.0, 3.0]
 
 
+def test_select_weight_known_answer():
+    """PyG >= 2.4 scores with tanh(s * w / ||w||): a negative scalar keeps the LOWEST GNN outputs."""
+    torch.manual_seed(0)
+    pool = O.SAGPooling(1, ratio=0.5, GNN=O.GraphConv, select_weight=True)
+    with torch.no_grad():
+        pool.gnn.lin_rel.weight.zero_(); pool.gnn.lin_rel.bias.zero_(); pool.gnn.lin_root.weight.fill_(1.0)   # s = x
+        pool.select.weight.fill_(-0.25)
+    x = torch.tensor([[0.3], [-1.0], [2.0], [0.1]])
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    out = pool(x, ei, None, torch.zeros(4, dtype=torch.long))
+    assert out[4].tolist() == [1, 3]                                      # lowest two: -1.0, 0.1
+    assert torch.allclose(out[5], torch.tanh(torch.tensor([1.0, -0.1])))  # score = tanh(-s)
+    assert torch.allclose(out[0], x[out[4]] * out[5].view(-1, 1))
+    with torch.no_grad():
+        pool.select.weight.fill_(3.0)                                     # only the sign of w matters
+    assert pool(x, ei, None, torch.zeros(4, dtype=torch.long))[4].tolist() == [2, 0]
+    assert "select.weight" in pool.state_dict()
+
+
 def test_kl_and_reparam_invariants():
     z = torch.zeros(9, 4)
     assert OM.kl_divergence(z, z).item() == 0.0
