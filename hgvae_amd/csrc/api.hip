@@ -13,4 +13,4 @@ void hgv_set_error(const char* fmt, ...) {
 extern "C" const char* hgv_last_error(void) { return g_err; }
 
 // ABI version: bumped whenever an exported signature changes.
-extern "C" int hgv_version(void) { return 1; }
+extern "C" int hgv_version(void) { return 2; }

@@ -1,251 +1,377 @@
-// Edge softmax for single-head graph attention, forward and backward, over the by-target CSR
-// of the loop-augmented graph (edges without self loops, then one loop per node).
+// Single-head graph attention over the by-target CSR of the loop-augmented graph (edges without self
+// loops, then one loop per node): edge softmax, attention dropout and the weighted neighbour sum in ONE
+// kernel per direction; nothing per-edge is written to memory.
 //
 // Reference: GATConv(hidden, hidden, heads=1, dropout=0.49) at
 // gvae/gvae_skipcon_attention.py:68,109 (PyG defaults negative_slope=0.2, add_self_loops):
-//   e_k     = leaky_relu(a_src[col_k] + a_dst[i], slope)          k in row i
-//   alpha_k = exp(e_k - max_row e) / (sum_row exp(e - max) + 1e-16)
-//   alpha'_k = dropout(alpha_k)    (mask indexed by the position of the edge in the edge LIST)
-// The weighted sum out_i = sum_k alpha'_k * xw[col_k] is the aggregation kernel with edge weights.
+//   e_k      = leaky_relu(a_src[col_k] + a_dst[i], slope)            k in row i
+//   alpha_k  = exp(e_k - max_row e) / (sum_row exp(e - max) + 1e-16)
+//   alpha'_k = dropout(alpha_k)        (mask indexed by the position of the edge in the edge LIST)
+//   out_i    = sum_k alpha'_k * xw[col_k] + bias
 //
-// Rows are handled by groups of 8 lanes (8 rows per wave); a row of any length is strided over
-// by its group, reductions by __shfl_xor inside the group.  No atomics.
+// Forward (k_gat_fwd): a group of L lanes owns a target row (the mapping of the aggregation kernel: lane l
+// keeps 16-byte feature chunks l, l + L, ...).  The logits of a row only touch col / a_src (4 bytes per
+// edge), so the row maximum and the normaliser take two cheap sweeps over them; the third sweep forms the
+// weights L edges at a time (one edge per lane), broadcasts them with ds_bpermute and accumulates the
+// gathered rows of xw.  Per row it keeps (max, normaliser) for the backward pass.
+//
+// Backward: with dad_k = <g_i, xw[col_k]>, S_i = sum_k alpha'_k dad_k and lk_k = d leaky / d raw,
+//   d logit_k = (alpha'_k dad_k - alpha_k S_i) lk_k,   d a_dst[i] = sum_k d logit_k,   d a_src[j] = sum over
+//   the out-edges of j,   d xw[j] = sum over the out-edges (j -> i) of alpha'_k g_i.
+// k_gat_bwd_rows walks the by-target CSR (gathers xw rows against the row's g_i held in registers) and
+// writes S_i and d a_dst[i] = sum alpha' dad lk - S_i sum alpha lk.  k_gat_bwd_cols walks the by-source
+// CSR: it holds xw[j] in registers, gathers g_i once per edge for both the dot product and the weighted
+// sum, and recomputes alpha / the keep decision of every edge from (a_src[j], a_dst[i], max_i, normaliser_i,
+// edge id), so no per-edge array and no permutation between the two CSR orders is needed.  No atomics.
 #include "common.h"
 
 namespace {
 
-constexpr int GL = 8;  // lanes per row
-
-__device__ __forceinline__ float grp_max(float v) {
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, GL));
-    return v;
-}
-__device__ __forceinline__ float grp_sum(float v) {
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, GL);
-    return v;
-}
 __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? v : v * slope; }
 
-__global__ __launch_bounds__(256) void k_gat_softmax_fwd(const int32_t* __restrict__ rowptr,
-                                                         const int32_t* __restrict__ col,
-                                                         const int32_t* __restrict__ perm, int64_t N,
-                                                         const float* __restrict__ a_src, int64_t lds_,
-                                                         const float* __restrict__ a_dst, int64_t ldd_, float slope,
-                                                         float p, float scale, const uint8_t* __restrict__ mask,
-                                                         int use_philox, uint64_t seed, uint64_t offset0,
-                                                         const uint64_t* __restrict__ offset_dev,
-                                                         float* __restrict__ alpha, float* __restrict__ alpha_drop) {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
-    const int lr = threadIdx.x & (GL - 1);
-    if (row >= N) return;
-    const int start = rowptr[row], end = rowptr[row + 1];
-    const float ad = a_dst[row * ldd_];
-    float m = -INFINITY;
-    for (int k = start + lr; k < end; k += GL) m = fmaxf(m, leaky(a_src[(int64_t)col[k] * lds_] + ad, slope));
-    m = grp_max(m);
-    if (end == start) return;
-    float s = 0.f;
-    for (int k = start + lr; k < end; k += GL) s += expf(leaky(a_src[(int64_t)col[k] * lds_] + ad, slope) - m);
-    s = grp_sum(s) + 1e-16f;
-    const HgvPhilox ph(seed);
-    const uint64_t offset = offset0 + (offset_dev ? offset_dev[0] : 0ull);
-    for (int k = start + lr; k < end; k += GL) {
-        const float al = expf(leaky(a_src[(int64_t)col[k] * lds_] + ad, slope) - m) / s;
-        alpha[k] = al;
-        float keep = 1.f;
-        if (p > 0.f) {
-            const uint32_t eid = (uint32_t)perm[k];
-            if (mask) keep = mask[eid] ? scale : 0.f;
-            else if (use_philox) {
-                const uint4 r = ph(eid, 0x6A7u, (uint32_t)offset, (uint32_t)(offset >> 32));
-                keep = hgv_u01(r.x) >= p ? scale : 0.f;
-            }
-        }
-        alpha_drop[k] = al * keep;
-    }
+struct GatArgs {
+    const int32_t* rowptr; const int32_t* col; const int32_t* perm; int64_t N;
+    const float* a_src; int64_t lds_; const float* a_dst; int64_t ldd_;
+    float slope, p, scale; const uint8_t* mask; int mode;       // mode 0: no dropout, 1: explicit mask, 2: Philox
+    uint64_t seed, offset; const uint64_t* offset_dev;
+    int C, nchunks, lshift;
+    const float* xw; int64_t ldx;
+    const float* g; int64_t ldg;
+    const float* bias;
+    float* out; int64_t ldo;            // forward: out; backward over sources: d xw
+    float* row_max; float* row_den;     // per target row: max logit, sum exp + 1e-16
+    float* S;                           // per target row: sum_k alpha'_k dad_k
+    float* da;                          // rows kernel: d a_dst; cols kernel: d a_src
+};
+
+// keep multiplier (0 or 1/(1-p)) of the edge with edge-list position eid
+__device__ __forceinline__ float edge_keep(const GatArgs& a, uint32_t eid, uint64_t off) {
+    if (a.mode == 0) return 1.f;
+    if (a.mode == 1) return a.mask[eid] ? a.scale : 0.f;
+    const HgvPhilox ph(a.seed);
+    const uint4 r = ph(eid, 0x6A7u, (uint32_t)off, (uint32_t)(off >> 32));
+    return hgv_u01(r.x) >= a.p ? a.scale : 0.f;
 }
 
-// dad[k] = <g[i,:], xw[col_k,:]> for every CSR position k of row i.  A group of L lanes owns a
-// row; each lane keeps its 4-float chunks of g[i,:] in registers and the group reduces per edge.
-__global__ __launch_bounds__(256) void k_gat_bwd_dot(const int32_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ col, int64_t N,
-                                                     const float* __restrict__ g, int64_t ldg,
-                                                     const float* __restrict__ xw, int64_t ldx, int C, int lshift,
-                                                     float* __restrict__ dad) {
-    const int lane = threadIdx.x & 63;
-    const int L = 1 << lshift;
-    const int lr = lane & (L - 1);
-    const int64_t wave = (int64_t)hgv_xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
-    const int64_t row = wave * (64 >> lshift) + (lane >> lshift);
-    if (row >= N) return;
-    const int start = rowptr[row], end = rowptr[row + 1];
-    for (int k = start; k < end; ++k) {
-        const int64_t j = col[k];
-        float acc = 0.f;
-        for (int c = lr; c < C; c += L) acc += g[row * ldg + c] * xw[j * ldx + c];
+__device__ __forceinline__ float grp_sum(float v, int L) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            if (o < L) acc += __shfl_xor(acc, o, 64);
-        if (lr == 0) dad[k] = acc;
-    }
+    for (int o = 32; o > 0; o >>= 1)
+        if (o < L) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float grp_max(float v, int L) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        if (o < L) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
-// The same dot products with 16-byte accesses: a group of L lanes owns a row, lane l keeps the 4-float
-// chunks l, l + L, ... (CPL of them) of g[i,:] in registers; neighbour indices are fetched L at a time
-// and broadcast; two edges are in flight per group and reduced together.  Needs 16-byte aligned rows.
-template <int CPL>
-__global__ __launch_bounds__(128) void k_gat_bwd_dot4(const int32_t* __restrict__ rowptr,
-                                                      const int32_t* __restrict__ col, int64_t N,
-                                                      const float* __restrict__ g, int64_t ldg,
-                                                      const float* __restrict__ xw, int64_t ldx, int C, int lshift,
-                                                      float* __restrict__ dad) {
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ void axpy4(float4& acc, float w, const float4& v) {
+    acc.x = __fadd_rn(acc.x, __fmul_rn(w, v.x)); acc.y = __fadd_rn(acc.y, __fmul_rn(w, v.y));
+    acc.z = __fadd_rn(acc.z, __fmul_rn(w, v.z)); acc.w = __fadd_rn(acc.w, __fmul_rn(w, v.w));
+}
+
+// row of the thread's group (two waves per workgroup, XCD-aware block order); false when past the end
+__device__ __forceinline__ bool group_row(const GatArgs& a, int64_t& row, int& lr, int& L) {
     const int lane = threadIdx.x & 63;
-    const int L = 1 << lshift;
-    const int lr = lane & (L - 1);
+    L = 1 << a.lshift;
+    lr = lane & (L - 1);
     const int64_t wave = (int64_t)hgv_xcd_remap(blockIdx.x, gridDim.x) * 2 + (threadIdx.x >> 6);
-    const int64_t row = wave * (64 >> lshift) + (lane >> lshift);
-    if (row >= N) return;
-    const int nchunks = (C + 3) >> 2;
-    float4 gr[CPL];
-    int coff[CPL];
+    row = wave * (64 >> a.lshift) + (lane >> a.lshift);
+    return row < a.N;
+}
+
+// the lane's CPL chunks of row `r` of `base`; columns past C and chunks past the row read as zeros
+template <int CPL>
+__device__ __forceinline__ void load_own_row(const float* base, int64_t ld, int64_t r, int C, int nchunks, int lr, int L,
+                                             float4 (&v)[CPL], int (&coff)[CPL], bool (&owns)[CPL]) {
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         const int c = lr + q * L;
-        coff[q] = (c < nchunks ? c : 0) * 4;
-        float4 v = *reinterpret_cast<const float4*>(g + row * ldg + coff[q]);
-        // columns past C (row padding) and chunks past the row count as zeros
-        if (c >= nchunks) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (coff[q] + 1 >= C) v.y = 0.f;
-        if (coff[q] + 2 >= C) v.z = 0.f;
-        if (coff[q] + 3 >= C) v.w = 0.f;
-        gr[q] = v;
+        owns[q] = c < nchunks;
+        coff[q] = (owns[q] ? c : 0) * 4;
+        float4 t = *reinterpret_cast<const float4*>(base + r * ld + coff[q]);
+        if (!owns[q]) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (coff[q] + 1 >= C) t.y = 0.f;
+        if (coff[q] + 2 >= C) t.z = 0.f;
+        if (coff[q] + 3 >= C) t.w = 0.f;
+        v[q] = t;
     }
-    const int start = rowptr[row], end = rowptr[row + 1];
+}
+
+template <int CPL>
+__global__ __launch_bounds__(128) void k_gat_fwd(const GatArgs a) {
+    int64_t row; int lr, L;
+    if (!group_row(a, row, lr, L)) return;
+    const int start = a.rowptr[row], end = a.rowptr[row + 1];
+    const float ad = a.a_dst[row * a.ldd_];
+    const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
+    float m = -INFINITY;
+    for (int k = start + lr; k < end; k += L) m = fmaxf(m, leaky(a.a_src[(int64_t)a.col[k] * a.lds_] + ad, a.slope));
+    m = grp_max(m, L);
+    float s = 0.f;
+    for (int k = start + lr; k < end; k += L) s += expf(leaky(a.a_src[(int64_t)a.col[k] * a.lds_] + ad, a.slope) - m);
+    s = grp_sum(s, L) + 1e-16f;
+
+    bool owns[CPL]; int coff[CPL]; float4 acc[CPL];
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        const int c = lr + q * L;
+        owns[q] = c < a.nchunks;
+        coff[q] = (owns[q] ? c : a.nchunks - 1) * 4;
+        acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int base = start; base < end; base += L) {
         const int k = base + lr;
-        const int my_col = k < end ? col[k] : 0;
+        int my_col = 0; float my_w = 0.f;
+        if (k < end) {
+            my_col = a.col[k];
+            const float al = expf(leaky(a.a_src[(int64_t)my_col * a.lds_] + ad, a.slope) - m) / s;
+            my_w = al * edge_keep(a, (uint32_t)a.perm[k], off);
+        }
         const int cnt = min(L, end - base);
-        for (int j = 0; j < cnt; j += 2) {
-            const float* r0 = xw + (int64_t)__shfl(my_col, j, L) * ldx;
-            const float* r1 = xw + (int64_t)__shfl(my_col, min(j + 1, cnt - 1), L) * ldx;
+        for (int j = 0; j < cnt; j += 2) {                 // two neighbour rows in flight; adds stay in segment order
+            const int j1 = min(j + 1, cnt - 1);
+            const float* r0 = a.xw + (int64_t)__shfl(my_col, j, L) * a.ldx;
+            const float* r1 = a.xw + (int64_t)__shfl(my_col, j1, L) * a.ldx;
+            const float w0 = __shfl(my_w, j, L), w1 = j + 1 < cnt ? __shfl(my_w, j1, L) : 0.f;
             float4 v0[CPL], v1[CPL];
 #pragma unroll
             for (int q = 0; q < CPL; ++q) {
                 v0[q] = *reinterpret_cast<const float4*>(r0 + coff[q]);
                 v1[q] = *reinterpret_cast<const float4*>(r1 + coff[q]);
             }
-            float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) {
-                a0 += gr[q].x * v0[q].x + gr[q].y * v0[q].y + gr[q].z * v0[q].z + gr[q].w * v0[q].w;
-                a1 += gr[q].x * v1[q].x + gr[q].y * v1[q].y + gr[q].z * v1[q].z + gr[q].w * v1[q].w;
-            }
+            for (int q = 0; q < CPL; ++q) axpy4(acc[q], w0, v0[q]);
+            if (j + 1 < cnt) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                if (o < L) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
-            }
-            if (lr == 0) {
-                dad[base + j] = a0;
-                if (j + 1 < cnt) dad[base + j + 1] = a1;
+                for (int q = 0; q < CPL; ++q) axpy4(acc[q], w1, v1[q]);
             }
         }
     }
-}
-
-// softmax + dropout + leaky-relu backward per row:
-//   dalpha_k = dad[k] * keep_k ; S = sum_k alpha_k dalpha_k ; de_k = alpha_k (dalpha_k - S)
-//   dl_k = de_k * (raw_k > 0 ? 1 : slope) ; da_dst[i] = sum_k dl_k ; dl[k] is scattered to sources later
-__global__ __launch_bounds__(256) void k_gat_softmax_bwd(const int32_t* __restrict__ rowptr,
-                                                         const int32_t* __restrict__ col, int64_t N,
-                                                         const float* __restrict__ a_src, int64_t lds_,
-                                                         const float* __restrict__ a_dst, int64_t ldd_, float slope,
-                                                         const float* __restrict__ alpha,
-                                                         const float* __restrict__ alpha_drop,
-                                                         const float* __restrict__ dad, float* __restrict__ dl,
-                                                         float* __restrict__ da_dst) {
-    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
-    const int lr = threadIdx.x & (GL - 1);
-    if (row >= N) return;
-    const int start = rowptr[row], end = rowptr[row + 1];
-    // keep_k = alpha_drop_k / alpha_k is 0 or scale; alpha_k * dalpha_k = alpha_drop_k * dad_k
-    float S = 0.f;
-    for (int k = start + lr; k < end; k += GL) S += alpha_drop[k] * dad[k];
-    S = grp_sum(S);
-    const float ad = a_dst[row * ldd_];
-    float acc = 0.f;
-    for (int k = start + lr; k < end; k += GL) {
-        const float raw = a_src[(int64_t)col[k] * lds_] + ad;
-        const float de = alpha_drop[k] * dad[k] - alpha[k] * S;
-        const float v = de * (raw > 0.f ? 1.f : slope);
-        dl[k] = v;
-        acc += v;
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        if (owns[q]) {
+            float4 o = acc[q];
+            if (a.bias) {
+                const int c0 = coff[q];
+                o.x += a.bias[c0];
+                if (c0 + 1 < a.C) o.y += a.bias[c0 + 1];
+                if (c0 + 2 < a.C) o.z += a.bias[c0 + 2];
+                if (c0 + 3 < a.C) o.w += a.bias[c0 + 3];
+            }
+            if (coff[q] + 1 >= a.C) o.y = 0.f;
+            if (coff[q] + 2 >= a.C) o.z = 0.f;
+            if (coff[q] + 3 >= a.C) o.w = 0.f;
+            *reinterpret_cast<float4*>(a.out + row * a.ldo + coff[q]) = o;
+        }
     }
-    acc = grp_sum(acc);
-    if (lr == 0) da_dst[row] = acc;
+    if (lr == 0) { a.row_max[row] = m; a.row_den[row] = s; }
 }
 
-}  // namespace
+// by-target rows: S_i = sum_k alpha'_k <g_i, xw[col_k]>,  d a_dst[i] = sum_k (alpha'_k dad_k - alpha_k S_i) lk_k
+template <int CPL>
+__global__ __launch_bounds__(128) void k_gat_bwd_rows(const GatArgs a) {
+    int64_t row; int lr, L;
+    if (!group_row(a, row, lr, L)) return;
+    float4 gr[CPL]; int coff[CPL]; bool owns[CPL];
+    load_own_row<CPL>(a.g, a.ldg, row, a.C, a.nchunks, lr, L, gr, coff, owns);
+    const int start = a.rowptr[row], end = a.rowptr[row + 1];
+    const float ad = a.a_dst[row * a.ldd_], m = a.row_max[row], s = a.row_den[row];
+    const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
+    float S = 0.f, T1 = 0.f, T2 = 0.f;
+    for (int base = start; base < end; base += L) {
+        const int k = base + lr;
+        int my_col = 0; float al = 0.f, ap = 0.f, lk = 0.f;
+        if (k < end) {
+            my_col = a.col[k];
+            const float raw = a.a_src[(int64_t)my_col * a.lds_] + ad;
+            al = expf(leaky(raw, a.slope) - m) / s;
+            ap = al * edge_keep(a, (uint32_t)a.perm[k], off);
+            lk = raw > 0.f ? 1.f : a.slope;
+        }
+        const int cnt = min(L, end - base);
+        float my_dad = 0.f;
+        for (int j = 0; j < cnt; j += 2) {
+            const int j1 = min(j + 1, cnt - 1);
+            const float* r0 = a.xw + (int64_t)__shfl(my_col, j, L) * a.ldx;
+            const float* r1 = a.xw + (int64_t)__shfl(my_col, j1, L) * a.ldx;
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                d0 += dot4(gr[q], *reinterpret_cast<const float4*>(r0 + coff[q]));
+                d1 += dot4(gr[q], *reinterpret_cast<const float4*>(r1 + coff[q]));
+            }
+            d0 = grp_sum(d0, L); d1 = grp_sum(d1, L);
+            if (lr == j) my_dad = d0;
+            if (lr == j + 1) my_dad = d1;
+        }
+        S += ap * my_dad;
+        T1 += ap * my_dad * lk;
+        T2 += al * lk;
+    }
+    S = grp_sum(S, L); T1 = grp_sum(T1, L); T2 = grp_sum(T2, L);
+    if (lr == 0) { a.S[row] = S; a.da[row] = T1 - S * T2; }
+}
 
-extern "C" int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
-                                   const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst,
-                                   float slope, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
-                                   const uint64_t* offset_dev,
-                                   float* alpha, float* alpha_drop, hipStream_t stream) {
-    HGV_REQUIRE(N >= 0, HGV_EINVAL, "gat_softmax_fwd: negative N");
-    if (N == 0) return HGV_OK;
-    HGV_REQUIRE(rowptr && col && perm && a_src && a_dst && alpha && alpha_drop, HGV_EINVAL, "gat_softmax_fwd: null buffer");
-    HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "gat_softmax_fwd: dropout p outside [0,1)");
-    const float scale = 1.0f / (float)(1.0 - (double)p);
-    const int64_t blocks = hgv_cdiv(N * GL, 256);
-    hipLaunchKernelGGL(k_gat_softmax_fwd, dim3((unsigned)blocks), dim3(256), 0, stream, rowptr, col, perm, N, a_src,
-                       ld_src, a_dst, ld_dst, slope, p, scale, mask, (mask == nullptr && p > 0.f) ? 1 : 0, seed, offset, offset_dev,
-                       alpha, alpha_drop);
-    HGV_CHECK_LAUNCH("gat_softmax_fwd");
+// by-source rows (rowptr / col / perm of the transposed CSR): d xw[j] and d a_src[j]
+template <int CPL>
+__global__ __launch_bounds__(128) void k_gat_bwd_cols(const GatArgs a) {
+    int64_t row; int lr, L;
+    if (!group_row(a, row, lr, L)) return;
+    float4 xr[CPL], acc[CPL]; int coff[CPL]; bool owns[CPL];
+    load_own_row<CPL>(a.xw, a.ldx, row, a.C, a.nchunks, lr, L, xr, coff, owns);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int start = a.rowptr[row], end = a.rowptr[row + 1];
+    const float as = a.a_src[row * a.lds_];
+    const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
+    float dsum = 0.f;
+    for (int base = start; base < end; base += L) {
+        const int t = base + lr;
+        int my_col = 0; float al = 0.f, ap = 0.f, lk = 0.f, Si = 0.f;
+        if (t < end) {
+            my_col = a.col[t];                                    // target i of this out-edge
+            const float raw = as + a.a_dst[(int64_t)my_col * a.ldd_];
+            al = expf(leaky(raw, a.slope) - a.row_max[my_col]) / a.row_den[my_col];
+            ap = al * edge_keep(a, (uint32_t)a.perm[t], off);
+            lk = raw > 0.f ? 1.f : a.slope;
+            Si = a.S[my_col];
+        }
+        const int cnt = min(L, end - base);
+        float my_dad = 0.f;
+        for (int j = 0; j < cnt; j += 2) {
+            const int j1 = min(j + 1, cnt - 1);
+            const float* r0 = a.g + (int64_t)__shfl(my_col, j, L) * a.ldg;
+            const float* r1 = a.g + (int64_t)__shfl(my_col, j1, L) * a.ldg;
+            const float w0 = __shfl(ap, j, L), w1 = j + 1 < cnt ? __shfl(ap, j1, L) : 0.f;
+            float4 v0[CPL], v1[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                v0[q] = *reinterpret_cast<const float4*>(r0 + coff[q]);
+                v1[q] = *reinterpret_cast<const float4*>(r1 + coff[q]);
+            }
+            float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) { d0 += dot4(xr[q], v0[q]); d1 += dot4(xr[q], v1[q]); }
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) axpy4(acc[q], w0, v0[q]);
+            if (j + 1 < cnt) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) axpy4(acc[q], w1, v1[q]);
+            }
+            d0 = grp_sum(d0, L); d1 = grp_sum(d1, L);
+            if (lr == j) my_dad = d0;
+            if (lr == j + 1) my_dad = d1;
+        }
+        dsum += (ap * my_dad - al * Si) * lk;
+    }
+    dsum = grp_sum(dsum, L);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+        if (owns[q]) {
+            float4 o = acc[q];
+            if (coff[q] + 1 >= a.C) o.y = 0.f;
+            if (coff[q] + 2 >= a.C) o.z = 0.f;
+            if (coff[q] + 3 >= a.C) o.w = 0.f;
+            *reinterpret_cast<float4*>(a.out + row * a.ldo + coff[q]) = o;
+        }
+    }
+    if (lr == 0) a.da[row] = dsum;
+}
+
+bool vec4_ok(const float* p, int64_t ld, int nchunks) { return p && hgv_aligned(p, 16) && ld % 4 == 0 && ld >= (int64_t)nchunks * 4; }
+
+// lanes per row (>= 8 unless the row has fewer chunks) x chunks per lane (<= 4): the fewest lane slots
+void pick_lanes(int nchunks, int* ls, int* cpl) {
+    int64_t best = -1;
+    *ls = 6; *cpl = 4;
+    for (int l = 0; l <= 6; ++l) {
+        const int Lc = 1 << l;
+        if (Lc < 8 && Lc < nchunks) continue;
+        int c = (int)hgv_cdiv(nchunks, Lc);
+        if (c > 4) continue;
+        if (c < 1) c = 1;
+        if (best < 0 || (int64_t)Lc * c < best) { best = (int64_t)Lc * c; *ls = l; *cpl = c; }
+    }
+}
+
+int fill_common(GatArgs& a, const char* who, const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
+                const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
+                const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int C, int* cpl) {
+    HGV_REQUIRE(rowptr && col && perm && a_src && a_dst, HGV_EINVAL, "%s: null graph / logit buffer", who);
+    HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "%s: dropout p outside [0,1)", who);
+    HGV_REQUIRE(C > 0 && C <= 1024, HGV_EUNSUPPORTED, "%s: feature width %d outside (0, 1024]", who, C);
+    a.rowptr = rowptr; a.col = col; a.perm = perm; a.N = N;
+    a.a_src = a_src; a.lds_ = ld_src; a.a_dst = a_dst; a.ldd_ = ld_dst;
+    a.slope = slope; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
+    a.mask = mask; a.mode = p > 0.f ? (mask ? 1 : 2) : 0;
+    a.seed = seed; a.offset = offset; a.offset_dev = offset_dev;
+    a.C = C; a.nchunks = (C + 3) / 4;
+    pick_lanes(a.nchunks, &a.lshift, cpl);
     return HGV_OK;
 }
 
-extern "C" int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, int64_t N, const float* g, int64_t ldg,
-                           const float* xw, int64_t ldx, int C, const float* a_src, int64_t ld_src,
-                           const float* a_dst, int64_t ld_dst, float slope, const float* alpha,
-                           const float* alpha_drop, float* dad, float* dl, float* da_dst, hipStream_t stream) {
-    HGV_REQUIRE(N >= 0 && C > 0, HGV_EINVAL, "gat_bwd: bad sizes");
-    if (N == 0) return HGV_OK;
-    HGV_REQUIRE(rowptr && col && g && xw && a_src && a_dst && alpha && alpha_drop && dad && dl && da_dst, HGV_EINVAL,
-                "gat_bwd: null buffer");
-    HGV_REQUIRE(ldg >= C && ldx >= C, HGV_EINVAL, "gat_bwd: leading dimension < C");
-    const int nchunks = (C + 3) / 4;
-    if (hgv_aligned(g, 16) && hgv_aligned(xw, 16) && ldg % 4 == 0 && ldx % 4 == 0 && ldg >= nchunks * 4 && ldx >= nchunks * 4 &&
-        nchunks <= 256) {
-        // lanes per row (>= 8 unless the row is shorter) x chunks per lane (<= 4): fewest lane slots
-        int ls = 0, cpl = 4;
-        int64_t best = -1;
-        for (int l = 0; l <= 6; ++l) {
-            const int Lc = 1 << l;
-            if (Lc < 8 && Lc < nchunks) continue;
-            int c = (int)hgv_cdiv(nchunks, Lc);
-            if (c > 4) continue;
-            if (c < 1) c = 1;
-            if (best < 0 || (int64_t)Lc * c < best) { best = (int64_t)Lc * c; ls = l; cpl = c; }
-        }
-        const int rows_per_block = 2 * (64 >> ls);
-        const dim3 grid((unsigned)hgv_cdiv(N, rows_per_block)), block(128);
-        switch (cpl) {
-            case 1: hipLaunchKernelGGL(k_gat_bwd_dot4<1>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
-            case 2: hipLaunchKernelGGL(k_gat_bwd_dot4<2>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
-            case 3: hipLaunchKernelGGL(k_gat_bwd_dot4<3>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
-            default: hipLaunchKernelGGL(k_gat_bwd_dot4<4>, grid, block, 0, stream, rowptr, col, N, g, ldg, xw, ldx, C, ls, dad); break;
-        }
-    } else {
-        int ls = 0;
-        while ((1 << ls) < C && ls < 6) ++ls;
-        const int rows_per_block = 4 * (64 >> ls);
-        hipLaunchKernelGGL(k_gat_bwd_dot, dim3((unsigned)hgv_cdiv(N, rows_per_block)), dim3(256), 0, stream, rowptr, col, N,
-                           g, ldg, xw, ldx, C, ls, dad);
+
+#define HGV_GAT_LAUNCH(KERN, cpl, grid, stream, a)                                                   \
+    switch (cpl) {                                                                                   \
+        case 1: hipLaunchKernelGGL(KERN<1>, grid, dim3(128), 0, stream, a); break;                   \
+        case 2: hipLaunchKernelGGL(KERN<2>, grid, dim3(128), 0, stream, a); break;                   \
+        case 3: hipLaunchKernelGGL(KERN<3>, grid, dim3(128), 0, stream, a); break;                   \
+        default: hipLaunchKernelGGL(KERN<4>, grid, dim3(128), 0, stream, a); break;                  \
     }
-    hipLaunchKernelGGL(k_gat_softmax_bwd, dim3((unsigned)hgv_cdiv(N * GL, 256)), dim3(256), 0, stream, rowptr, col, N,
-                       a_src, ld_src, a_dst, ld_dst, slope, alpha, alpha_drop, dad, dl, da_dst);
+
+}  // namespace
+
+// out[i,:] = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k,:] (+ bias); row_max / row_den
+// [N] receive the row maximum of the logits and the softmax normaliser (sum + 1e-16) for hgv_gat_bwd.
+extern "C" int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N, const float* xw,
+                           int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst,
+                           float slope, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                           const uint64_t* offset_dev, const float* bias, float* out, int64_t ldo, float* row_max,
+                           float* row_den, hipStream_t stream) {
+    HGV_REQUIRE(N >= 0, HGV_EINVAL, "gat_fwd: negative N");
+    if (N == 0) return HGV_OK;
+    GatArgs a{}; int cpl;
+    const int rc = fill_common(a, "gat_fwd", rowptr, col, perm, N, a_src, ld_src, a_dst, ld_dst, slope, p, mask, seed, offset,
+                               offset_dev, C, &cpl);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(row_max && row_den, HGV_EINVAL, "gat_fwd: null row statistics buffer");
+    HGV_REQUIRE(vec4_ok(xw, ldx, a.nchunks) && vec4_ok(out, ldo, a.nchunks), HGV_EINVAL,
+                "gat_fwd: xw / out must be 16-byte aligned with leading dimensions that are multiples of 4 and cover ceil(C/4)*4 columns");
+    a.xw = xw; a.ldx = ldx; a.bias = bias; a.out = out; a.ldo = ldo; a.row_max = row_max; a.row_den = row_den;
+    const dim3 grid((unsigned)hgv_cdiv(N, 2 * (64 >> a.lshift)));
+    HGV_GAT_LAUNCH(k_gat_fwd, cpl, grid, stream, a)
+    HGV_CHECK_LAUNCH("gat_fwd");
+    return HGV_OK;
+}
+
+// Backward of hgv_gat_fwd for the output gradient g [N, C]: gxw [N, C] (d xw), da_src [N], da_dst [N].  The by-target
+// CSR (rowptr / col / perm) and the by-source CSR (rowptr_t / col_t / perm_t) of the same edge list, the forward's
+// noise arguments and its row_max / row_den are needed; S [N] is scratch.
+extern "C" int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* rowptr_t,
+                           const int32_t* col_t, const int32_t* perm_t, int64_t N, const float* g, int64_t ldg,
+                           const float* xw, int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst,
+                           int64_t ld_dst, float slope, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                           const uint64_t* offset_dev, const float* row_max, const float* row_den, float* S, float* gxw,
+                           int64_t ldgx, float* da_src, float* da_dst, hipStream_t stream) {
+    HGV_REQUIRE(N >= 0, HGV_EINVAL, "gat_bwd: negative N");
+    if (N == 0) return HGV_OK;
+    GatArgs a{}; int cpl;
+    int rc = fill_common(a, "gat_bwd", rowptr, col, perm, N, a_src, ld_src, a_dst, ld_dst, slope, p, mask, seed, offset,
+                         offset_dev, C, &cpl);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(rowptr_t && col_t && perm_t && row_max && row_den && S && da_src && da_dst, HGV_EINVAL, "gat_bwd: null buffer");
+    HGV_REQUIRE(vec4_ok(xw, ldx, a.nchunks) && vec4_ok(g, ldg, a.nchunks) && vec4_ok(gxw, ldgx, a.nchunks), HGV_EINVAL,
+                "gat_bwd: g / xw / gxw must be 16-byte aligned with leading dimensions that are multiples of 4 and cover ceil(C/4)*4 columns");
+    a.xw = xw; a.ldx = ldx; a.g = g; a.ldg = ldg;
+    a.row_max = const_cast<float*>(row_max); a.row_den = const_cast<float*>(row_den); a.S = S;
+    const dim3 grid((unsigned)hgv_cdiv(N, 2 * (64 >> a.lshift)));
+    a.da = da_dst;
+    HGV_GAT_LAUNCH(k_gat_bwd_rows, cpl, grid, stream, a)
+    a.rowptr = rowptr_t; a.col = col_t; a.perm = perm_t; a.out = gxw; a.ldo = ldgx; a.da = da_src;
+    HGV_GAT_LAUNCH(k_gat_bwd_cols, cpl, grid, stream, a)
     HGV_CHECK_LAUNCH("gat_bwd");
     return HGV_OK;
 }

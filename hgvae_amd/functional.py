@@ -760,55 +760,55 @@ def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 # single-head graph attention (edge softmax + weighted aggregation)
 # --------------------------------------------------------------------------------------
 class _GatAggregate(torch.autograd.Function):
-    """out_i = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k]
+    """out_i = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k] (+ bias)
 
-    over the loop-augmented graph ``lg``.  Inputs xw [N, C], a_src [N], a_dst [N].
+    over the loop-augmented graph ``lg``.  Inputs xw [N, C], a_src [N], a_dst [N].  One kernel forward,
+    two backward (one per CSR direction); the attention weights are recomputed, never stored.
     """
 
     @staticmethod
-    def forward(ctx, xw, a_src, a_dst, lg: Graph, slope, p, mask, seed, offset, ctr):
+    def forward(ctx, xw, a_src, a_dst, bias, lg: Graph, slope, p, mask, seed, offset, ctr):
         _lib.require_cuda(xw, a_src, a_dst)
         xw = as_padded(xw)
-        a_src, a_dst = a_src.contiguous(), a_dst.contiguous()
-        n, e = lg.num_nodes, lg.num_edges
+        n, c = lg.num_nodes, xw.size(1)
         csr = lg.by_dst
-        alpha = torch.empty(e, dtype=torch.float32, device=xw.device)
-        alpha_drop = torch.empty(e, dtype=torch.float32, device=xw.device)
-        _lib.call("hgv_gat_softmax_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n,
-                  a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(slope), float(p), _lib.ptr(mask), seed, offset, ctr,
-                  alpha.data_ptr(), alpha_drop.data_ptr(), _lib.stream())
-        out = new_padded(n, xw.size(1), xw.device, zero_pad=False)
-        _agg_launch(csr, n, xw, xw.size(1), 0, None, alpha_drop, None, None, out)
-        ctx.lg, ctx.slope = lg, slope
-        ctx.save_for_backward(xw, a_src, a_dst, alpha, alpha_drop)
+        dev = xw.device
+        row_max = torch.empty(n, dtype=torch.float32, device=dev)
+        row_den = torch.empty(n, dtype=torch.float32, device=dev)
+        out = new_padded(n, c, dev, zero_pad=False)
+        _lib.call("hgv_gat_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n, xw.data_ptr(), ld_of(xw),
+                  c, a_src.data_ptr(), a_src.stride(0), a_dst.data_ptr(), a_dst.stride(0), float(slope), float(p),
+                  _lib.ptr(mask), seed, offset, ctr, _lib.ptr(bias), out.data_ptr(), ld_of(out), row_max.data_ptr(),
+                  row_den.data_ptr(), _lib.stream())
+        ctx.lg, ctx.cfg = lg, (slope, p, seed, offset, ctr)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(xw, a_src, a_dst, row_max, row_den, mask)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xw, a_src, a_dst, alpha, alpha_drop = ctx.saved_tensors
+        xw, a_src, a_dst, row_max, row_den, mask = ctx.saved_tensors
         lg = ctx.lg
-        n, e, c = lg.num_nodes, lg.num_edges, xw.size(1)
+        slope, p, seed, offset, ctr = ctx.cfg
+        n, c = lg.num_nodes, xw.size(1)
         g = as_padded(g)
         csr, csr_t = lg.by_dst, lg.by_src
         dev = xw.device
-        dad = torch.empty(e, dtype=torch.float32, device=dev)
-        dl = torch.empty(e, dtype=torch.float32, device=dev)
+        scratch = torch.empty(n, dtype=torch.float32, device=dev)
+        da_src = torch.empty(n, dtype=torch.float32, device=dev)
         da_dst = torch.empty(n, dtype=torch.float32, device=dev)
-        _lib.call("hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), n, g.data_ptr(), ld_of(g), xw.data_ptr(),
-                  ld_of(xw), c, a_src.data_ptr(), 1, a_dst.data_ptr(), 1, float(ctx.slope), alpha.data_ptr(),
-                  alpha_drop.data_ptr(), dad.data_ptr(), dl.data_ptr(), da_dst.data_ptr(), _lib.stream())
-        t2f = lg.src_pos_to_dst_pos
-        # d xw (direct path): transposed weighted aggregation of g
         gxw = new_padded(n, c, dev, zero_pad=False)
-        _agg_launch(csr_t, n, g, c, 0, None, alpha_drop.index_select(0, t2f), None, None, gxw)
-        # d a_src[j] = sum of dl over the out-edges of j (F = 1 aggregation of ones with edge weights)
-        ones = torch.ones(n, 1, dtype=torch.float32, device=dev)
-        da_src = torch.empty(n, 1, dtype=torch.float32, device=dev)
-        _agg_launch(csr_t, n, ones, 1, 0, None, dl.index_select(0, t2f), None, None, da_src)
-        return gxw, da_src.view(n), da_dst, None, None, None, None, None, None, None
+        _lib.call("hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), csr_t.rowptr.data_ptr(),
+                  csr_t.col.data_ptr(), csr_t.perm.data_ptr(), n, g.data_ptr(), ld_of(g), xw.data_ptr(), ld_of(xw), c,
+                  a_src.data_ptr(), a_src.stride(0), a_dst.data_ptr(), a_dst.stride(0), float(slope), float(p),
+                  _lib.ptr(mask), seed, offset, ctr, row_max.data_ptr(), row_den.data_ptr(), scratch.data_ptr(),
+                  gxw.data_ptr(), ld_of(gxw), da_src.data_ptr(), da_dst.data_ptr(), _lib.stream())
+        gbias = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return gxw, da_src, da_dst, gbias, None, None, None, None, None, None, None
 
 
-def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, training: bool):
+def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, training: bool, bias=None):
+    """Attention-weighted neighbour sum of GATConv (+ bias); a_src / a_dst may be strided columns of one [N, 2] table."""
     mask, seed, offset, ctr = None, 0, 0, None
     if training and p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
@@ -816,7 +816,9 @@ def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, t
             mask = mask.view(-1)
     else:
         p = 0.0
-    return _GatAggregate.apply(xw, a_src, a_dst, loop_graph, slope, p, mask, seed, offset, ctr)
+    if a_src.dim() != 1 or a_dst.dim() != 1 or a_src.dtype != torch.float32 or a_dst.dtype != torch.float32:
+        raise _lib.HgvError("gat_aggregate: a_src / a_dst must be float32 vectors")
+    return _GatAggregate.apply(xw, a_src, a_dst, bias, loop_graph, slope, p, mask, seed, offset, ctr)
 
 
 # --------------------------------------------------------------------------------------

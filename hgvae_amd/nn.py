@@ -120,12 +120,12 @@ class GATConv(nn.Module):
             # (torch.mv runs a rocBLAS gemv that takes ~0.4 ms per call at 40 k x 256)
             att = torch.cat([self.att_src.view(1, -1), self.att_dst.view(1, -1)])
             ab = Fn.dual_linear(xw, att)
-            out = Fn.gat_aggregate(xw, ab[:, 0], ab[:, 1], lg, self.negative_slope, self.dropout, self.training)
+            return Fn.gat_aggregate(xw, ab[:, 0], ab[:, 1], lg, self.negative_slope, self.dropout, self.training,
+                                    bias=self.bias)
         else:
             raise NotImplementedError(
                 "heads > 1 is not supported: the reference's encoder only type-checks with heads=1 "
                 "(gvae/gvae_skipcon_attention.py:74,96)")
-        return out + self.bias
 
 
 class SelectTopK(nn.Module):

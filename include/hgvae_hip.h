@@ -156,22 +156,26 @@ int hgv_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws,
  *      gvae/gvae_skipcon_attention.py:68,109 (negative_slope 0.2, self loops added) ----------
  * CSR = by-target CSR of the loop-augmented edge list (edges minus self loops, then one loop per
  * node); perm maps CSR position -> index in that edge list (the index the dropout mask uses).
- *   alpha[k]      = softmax over row i of leaky_relu(a_src[col[k]] + a_dst[i])  (+1e-16 in the sum)
- *   alpha_drop[k] = alpha[k] * keep_k / (1-p)
- * The output rows are hgv_agg_fwd(..., edge_w = alpha_drop).  a_src / a_dst are read with an
- * element stride (ld_src / ld_dst) so one head of an [N, heads] table can be passed. */
-int hgv_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N,
-                        const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
-                        const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, float* alpha,
-                        float* alpha_drop,
-                        hgv_stream_t stream);
-/* Backward: dad[k] = <g[i,:], xw[col[k],:]>; dl[k] = gradient w.r.t. the pre-leaky logit of edge k;
- * da_dst[i] = sum_k dl[k].  (da_src is the sum of dl over each source's out-edges: hgv_agg_fwd on
- * the by-source CSR with F = 1.)  dad is scratch [E']. */
-int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, int64_t N, const float* g, int64_t ldg, const float* xw,
-                int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst,
-                float slope, const float* alpha, const float* alpha_drop, float* dad, float* dl, float* da_dst,
-                hgv_stream_t stream);
+ *   alpha_k  = softmax over row i of leaky_relu(a_src[col[k]] + a_dst[i])  (+1e-16 in the sum)
+ *   alpha'_k = alpha_k * keep_k / (1-p)     (mask: explicit uint8 [E'] by edge-list index, or Philox when null and p > 0)
+ *   out[i,:] = sum_k alpha'_k * xw[col[k],:] (+ bias)
+ * One kernel: softmax, dropout and the weighted sum per target row; no per-edge array is written.  row_max / row_den [N]
+ * receive the row maximum of the logits and the normaliser (sum + 1e-16) for the backward pass.  a_src / a_dst are read
+ * with an element stride (ld_src / ld_dst).  xw / out: 16-byte aligned, leading dimensions multiples of 4 that cover
+ * ceil(C/4)*4 columns; pad columns of out are written as zeros. */
+int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N, const float* xw, int64_t ldx,
+                int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
+                const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* bias,
+                float* out, int64_t ldo, float* row_max, float* row_den, hgv_stream_t stream);
+/* Backward (autograd of the above, loss.backward() gvae/gvae_skipcon_attention.py:181) for the output gradient g [N, C]:
+ * gxw [N, C] = d xw, da_src [N], da_dst [N].  Takes both CSRs of the same edge list (rowptr_t / col_t / perm_t = by
+ * source), the forward's noise arguments and row_max / row_den; S [N] is scratch.  Two kernels (one per CSR direction),
+ * each recomputing the attention weights of its edges; same layout contract as hgv_gat_fwd for g / xw / gxw. */
+int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* rowptr_t, const int32_t* col_t,
+                const int32_t* perm_t, int64_t N, const float* g, int64_t ldg, const float* xw, int64_t ldx, int C,
+                const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
+                const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* row_max,
+                const float* row_den, float* S, float* gxw, int64_t ldgx, float* da_src, float* da_dst, hgv_stream_t stream);
 
 /* ---- SAGPooling: autoencoder/vae_with_pool.py:25,36,39 and :42-50;
  *      autoencoder/vae_custom_pool.py:56-58 ------------------------------------------------

@@ -91,7 +91,7 @@ def main():
            "source": f"tools/pmc_bench.py: rocprofv3 --pmc <counter> -- python3 bench.py --workload {args.workload} "
                      f"--steps {{{lo},{hi}}} --warmup 2 (separate passes; per-step = difference / {hi - lo})",
            "units": "bytes; reads = FETCH_SIZE KB x 1024 x 2 (gfx950 counts 16-byte-per-lane reads at half), writes = WRITE_SIZE KB x 1024"}
-    agg = [k for k in per_disp if k.startswith(args.agg_kernel)]
+    agg = [k for k in per_disp if args.agg_kernel in k]
     if agg:
         k = agg[0]
         r = per_disp[k].get("FETCH_SIZE", 0.0) * 1024 * 2
@@ -100,7 +100,7 @@ def main():
                               "hbm_bytes_per_launch": int(r + w), "dispatches_per_step": disp.get(k)}
     proj = {}
     for tag, pref in (("nt", ("k_gemm_nt",)), ("tn", ("k_gemm_tn", "k_reduce_tn"))):
-        ks = [k for k in in_step if k.startswith(pref)]
+        ks = [k for k in in_step if any(p in k for p in pref)]
         if ks:
             proj[tag] = {"kernels": sorted(ks), "mfma_busy_frac": round(busy([k for k in ks if "k_gemm" in k]) or 0.0, 4),
                          "hbm_bytes_per_step": int(sum(rd(k) + wr(k) for k in ks)),
