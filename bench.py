@@ -237,10 +237,8 @@ def main():
 
     eager_step = step
     if args.graph:
-        if kind in ("pool", "custom_pool"):
-            raise SystemExit("the pooling variants size their outputs on the host and cannot be captured")
         from hgvae_amd.graphed import GraphedTrainStep
-        step = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, bucket=bucket,
+        step = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, loss_fn=loss_fn, bucket=bucket,
                                 seed=noise_seed, warmup=max(args.warmup, 1))
     note("workload and CSR ready; warm-up")
     for _ in range(args.warmup):

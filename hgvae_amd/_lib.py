@@ -40,9 +40,9 @@ SIGNATURES = {
     "hgv_gat_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _f32, _f32,
                               _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "hgv_topk_ws": (_sz, [_i64]),
-    "hgv_topk_perm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "hgv_topk_perm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "hgv_filter_adj_ws": (_sz, [_i64, _i64]),
-    "hgv_filter_adj": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "hgv_filter_adj": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "hgv_gather_rows": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "hgv_gather_rows_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hgv_gather_i64": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),

@@ -43,6 +43,51 @@ __global__ void k_topk_select(const int32_t* __restrict__ ids_sorted, const int6
     }
 }
 
+// One workgroup per graph whose node count fits the LDS table: the graph's (descending-score key, local node index)
+// pairs are sorted as 64-bit words by a bitonic network in LDS (total order: ties in the score fall back to the
+// ascending node index, the order of a stable sort) and the first k[g] entries go straight to perm.
+constexpr int SEG_CAP = 16384;             // 128 KB of 64-bit words
+constexpr int SEG_THREADS = 1024;
+
+__global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __restrict__ score, const int64_t* __restrict__ ptr,
+                                                              const int64_t* __restrict__ k, const int64_t* __restrict__ kptr,
+                                                              int64_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char seg_raw[];
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(seg_raw);
+    const int g = blockIdx.x;
+    const int64_t lo = ptr[g];
+    const int n = (int)(ptr[g + 1] - lo);
+    const int kg = (int)k[g];
+    if (n <= 0 || kg <= 0) return;
+    int m = 1;
+    while (m < n) m <<= 1;                 // table size: next power of two, padded with keys that sort last
+    for (int i = threadIdx.x; i < m; i += SEG_THREADS) {
+        unsigned long long w = ~0ull;
+        if (i < n) {
+            const float sc = score[lo + i] + 0.0f;                       // -0.0 -> +0.0: torch.sort treats them as equal
+            uint32_t u = __float_as_uint(sc);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);              // ascending in the score
+            w = ((unsigned long long)(~u) << 32) | (unsigned)i;           // descending score, then ascending index
+        }
+        tab[i] = w;
+    }
+    __syncthreads();
+    for (int size = 2; size <= m; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (m >> 1); t += SEG_THREADS) {
+                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));    // lower element of pair t
+                const int j = i | stride;
+                const bool up = (i & size) == 0;
+                const unsigned long long a = tab[i], b = tab[j];
+                if ((a > b) == up) { tab[i] = b; tab[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t base = kptr[g];
+    for (int r = threadIdx.x; r < kg; r += SEG_THREADS) perm[base + r] = lo + (int64_t)(tab[r] & 0xffffffffull);
+}
+
 __global__ void k_fill_i32(int32_t* __restrict__ p, int64_t n, int32_t v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -58,19 +103,48 @@ __global__ void k_edge_flags(const int64_t* __restrict__ ei, int64_t ld_row, int
 __global__ void k_edge_compact(const int64_t* __restrict__ ei, int64_t ld_row, int64_t ld_col, int64_t E,
                                const int32_t* __restrict__ map, const int32_t* __restrict__ flags,
                                const int32_t* __restrict__ pos, int64_t* __restrict__ out, int64_t ld_out,
-                               int32_t* __restrict__ kept_ids, int32_t* __restrict__ count) {
+                               int32_t* __restrict__ kept_ids, int32_t* __restrict__ count, int fill_tail) {
+    const int32_t total = pos[E - 1] + flags[E - 1];
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x) {
         if (flags[e]) {
             const int32_t q = pos[e];
             out[q] = map[ei[e * ld_col]];
             out[ld_out + q] = map[ei[ld_row + e * ld_col]];
             if (kept_ids) kept_ids[q] = (int32_t)e;
+        } else if (fill_tail) {
+            // the dropped edges number E - total: dropped edge e is the (e - pos[e])-th of them and zeroes that tail slot,
+            // so a caller that works on the whole capacity without reading count back sees valid (zero) indices
+            const int64_t q = (int64_t)total + (e - pos[e]);
+            out[q] = 0;
+            out[ld_out + q] = 0;
+            if (kept_ids) kept_ids[q] = 0;
         }
-        if (e == E - 1) count[0] = pos[e] + flags[e];
+        if (e == E - 1) count[0] = total;
     }
 }
 
-// out[q, :] = x[idx[q], :] * (scale ? scale[idx[q]] : 1)
+// out[q, :] = x[idx[q], :] * (scale ? scale[idx[q]] : 1) with 16-byte accesses: a group of L lanes owns a gathered row,
+// lane l moves the 4-float chunks l, l + L, ...; pad columns of the output are written as zeros.
+__global__ __launch_bounds__(256) void k_gather_rows4(const float* __restrict__ x, int64_t ldx,
+                                                      const int64_t* __restrict__ idx, const float* __restrict__ scale,
+                                                      int64_t K, int F, int lshift, float* __restrict__ out, int64_t ldo) {
+    const int L = 1 << lshift, lr = threadIdx.x & (L - 1);
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> lshift;
+    if (q >= K) return;
+    const int64_t r = idx[q];
+    const float s = scale ? scale[r] : 1.f;
+    const int nchunks = (F + 3) >> 2;
+    for (int c = lr; c < nchunks; c += L) {
+        float4 v = *reinterpret_cast<const float4*>(x + r * ldx + 4 * c);
+        if (scale) { v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+        if (4 * c + 1 >= F) v.y = 0.f;
+        if (4 * c + 2 >= F) v.z = 0.f;
+        if (4 * c + 3 >= F) v.w = 0.f;
+        *reinterpret_cast<float4*>(out + q * ldo + 4 * c) = v;
+    }
+}
+
+// scalar variant for layouts without 16-byte aligned rows
 __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ x, int64_t ldx,
                                                      const int64_t* __restrict__ idx, const float* __restrict__ scale,
                                                      int64_t K, int F, float* __restrict__ out, int64_t ldo) {
@@ -137,11 +211,29 @@ extern "C" size_t hgv_topk_ws(int64_t N) {
 // Per-graph top-k.  batch [N] int64 (graph id per node, ascending), ptr [B+1], k [B], kptr [B+1]
 // (exclusive cumsum of k) are device arrays prepared by the caller; perm gets kptr[B] entries.
 extern "C" int hgv_topk_perm(const float* score, const int64_t* batch, const int64_t* ptr, const int64_t* k,
-                             const int64_t* kptr, int64_t N, int64_t B, int64_t* perm, void* ws, size_t ws_bytes,
-                             hipStream_t stream) {
+                             const int64_t* kptr, int64_t N, int64_t B, int64_t max_nodes, int64_t* perm, void* ws,
+                             size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(N >= 0 && B >= 0, HGV_EINVAL, "topk_perm: negative size");
     if (N == 0) return HGV_OK;
-    HGV_REQUIRE(score && batch && ptr && k && kptr && perm && ws, HGV_EINVAL, "topk_perm: null buffer");
+    HGV_REQUIRE(score && batch && ptr && k && kptr && perm, HGV_EINVAL, "topk_perm: null buffer");
+    if (max_nodes > 0 && max_nodes <= SEG_CAP && B <= 65535 * 16) {
+        // every graph fits one workgroup's LDS table: one launch, no global sort passes
+        int m = 1;
+        while (m < max_nodes) m <<= 1;
+        static bool raised[64] = {false};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!raised[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_segment),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, SEG_CAP * 8);
+            HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "topk_perm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+            raised[dev] = true;
+        }
+        hipLaunchKernelGGL(k_topk_segment, dim3((unsigned)B), dim3(SEG_THREADS), (size_t)m * 8, stream, score, ptr, k, kptr, perm);
+        HGV_CHECK_LAUNCH("topk_perm(segmented)");
+        return HGV_OK;
+    }
+    HGV_REQUIRE(ws != nullptr, HGV_EINVAL, "topk_perm: null workspace");
     HGV_REQUIRE(ws_bytes >= hgv_topk_ws(N) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "topk_perm: workspace too small or misaligned");
     char* p = (char*)ws;
     const size_t seg = hgv_align256((size_t)N * 4);
@@ -173,10 +265,11 @@ extern "C" size_t hgv_filter_adj_ws(int64_t E, int64_t N) {
 // filter_adj: edges (any strides) whose two ends are in perm, relabelled to positions in perm, order
 // preserved.  out_ei [2, cap] int64 with row stride ld_out (cap >= E is always enough); kept_ids
 // (nullable, [cap]) receives the original edge id of every kept edge (to gather edge_attr);
-// count[0] receives the number of kept edges.
+// count[0] receives the number of kept edges.  fill_tail != 0 additionally writes zeros to slots [count, E) of out_ei /
+// kept_ids (cap >= E then), for callers that keep working on the whole capacity without reading count back.
 extern "C" int hgv_filter_adj(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int64_t E, int64_t N,
                               const int64_t* perm, int64_t K, int64_t* out_ei, int64_t ld_out, int32_t* kept_ids,
-                              int32_t* count, void* ws, size_t ws_bytes, hipStream_t stream) {
+                              int32_t* count, int fill_tail, void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(E >= 0 && N >= 0 && K >= 0, HGV_EINVAL, "filter_adj: negative size");
     HGV_REQUIRE(count != nullptr, HGV_EINVAL, "filter_adj: count is null");
     if (E == 0) {
@@ -196,7 +289,7 @@ extern "C" int hgv_filter_adj(const int64_t* edge_index, int64_t ld_row, int64_t
     int rc = hgv_exclusive_scan_i32(flags, pos, E, p, hgv_exclusive_scan_ws(E), stream);
     if (rc != HGV_OK) return rc;
     hipLaunchKernelGGL(k_edge_compact, dim3(grid1d(E)), dim3(256), 0, stream, edge_index, ld_row, ld_col, E, map, flags,
-                       pos, out_ei, ld_out, kept_ids, count);
+                       pos, out_ei, ld_out, kept_ids, count, fill_tail);
     HGV_CHECK_LAUNCH("filter_adj");
     return HGV_OK;
 }
@@ -206,7 +299,15 @@ extern "C" int hgv_gather_rows(const float* x, int64_t ldx, const int64_t* idx, 
     HGV_REQUIRE(K >= 0 && F >= 0, HGV_EINVAL, "gather_rows: negative size");
     if (K == 0 || F == 0) return HGV_OK;
     HGV_REQUIRE(x && idx && out && ldx >= F && ldo >= F, HGV_EINVAL, "gather_rows: null/short buffer");
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid1d(K * F)), dim3(256), 0, stream, x, ldx, idx, scale, K, F, out, ldo);
+    const int nchunks = (F + 3) / 4;
+    if (hgv_aligned(x, 16) && hgv_aligned(out, 16) && ldx % 4 == 0 && ldo % 4 == 0 && ldx >= 4 * nchunks && ldo >= 4 * nchunks) {
+        int ls = 0;
+        while ((1 << ls) < nchunks && ls < 4) ++ls;        // up to 16 lanes per row: 35 chunks = 16 lanes x 3 turns
+        hipLaunchKernelGGL(k_gather_rows4, dim3((unsigned)hgv_cdiv(K << ls, 256)), dim3(256), 0, stream, x, ldx, idx, scale, K, F,
+                           ls, out, ldo);
+    } else {
+        hipLaunchKernelGGL(k_gather_rows, dim3(grid1d(K * F)), dim3(256), 0, stream, x, ldx, idx, scale, K, F, out, ldo);
+    }
     HGV_CHECK_LAUNCH("gather_rows");
     return HGV_OK;
 }

@@ -824,26 +824,77 @@ def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, t
 # --------------------------------------------------------------------------------------
 # pooling helpers
 # --------------------------------------------------------------------------------------
-def topk_perm(score: torch.Tensor, ratio: float, batch: torch.Tensor, num_graphs: Optional[int] = None):
-    """Per-graph top ceil(ratio * n_g) nodes by descending score (ties: ascending node id)."""
+class _BatchPlan:
+    """Sizes that depend only on the batch vector and the pooling ratio: graph boundaries, kept counts and their
+    prefix sums (device arrays) and the host-side totals.  Building one costs a host synchronisation; plans are
+    cached per batch tensor object, so a training loop that reuses its batches (or replays a captured step) pays
+    it once."""
+    __slots__ = ("num_graphs", "ptr", "k", "kptr", "total", "max_nodes")
+
+    def __init__(self, batch: torch.Tensor, ratio: float, dtype, num_graphs: Optional[int]):
+        n = batch.numel()
+        if num_graphs is None:
+            num_graphs = int(batch.max().item()) + 1 if n else 0
+        n_g = torch.bincount(batch, minlength=num_graphs)
+        k_g = (float(ratio) * n_g.to(dtype)).ceil().to(torch.long)
+        self.num_graphs = num_graphs
+        self.ptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=batch.device)
+        self.ptr[1:] = torch.cumsum(n_g, 0)
+        self.k = k_g
+        self.kptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=batch.device)
+        self.kptr[1:] = torch.cumsum(k_g, 0)
+        sizes = torch.stack([self.kptr[-1], n_g.max() if num_graphs else self.kptr[-1]]).tolist()   # one sync
+        self.total, self.max_nodes = int(sizes[0]), int(sizes[1])
+
+
+_plan_cache: "dict[tuple, tuple]" = {}
+
+
+def batch_plan(batch: torch.Tensor, ratio: float, dtype=torch.float32, num_graphs: Optional[int] = None) -> _BatchPlan:
+    import weakref
+    key = (id(batch), float(ratio), dtype)
+    hit = _plan_cache.get(key)
+    if hit is not None and hit[0]() is batch and hit[1] == batch._version:
+        return hit[2]
+    plan = _BatchPlan(batch, ratio, dtype, num_graphs)
+    _plan_cache[key] = (weakref.ref(batch, lambda _r, k=key: _plan_cache.pop(k, None)), batch._version, plan)
+    return plan
+
+
+def topk_perm(score: torch.Tensor, ratio: float, batch: torch.Tensor, num_graphs: Optional[int] = None,
+              global_sort: bool = False):
+    """Per-graph top ceil(ratio * n_g) nodes by descending score (ties: ascending node id).  Graphs of up to 16384
+    nodes are sorted by one workgroup each in LDS; larger ones (or ``global_sort``) by radix passes over all scores."""
     _lib.require_cuda(score, batch)
     n = score.numel()
-    if num_graphs is None:
-        num_graphs = int(batch.max().item()) + 1 if n else 0
-    n_g = torch.bincount(batch, minlength=num_graphs)
-    k_g = (float(ratio) * n_g.to(score.dtype)).ceil().to(torch.long)
-    ptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=score.device)
-    ptr[1:] = torch.cumsum(n_g, 0)
-    kptr = torch.zeros(num_graphs + 1, dtype=torch.long, device=score.device)
-    kptr[1:] = torch.cumsum(k_g, 0)
-    total = int(kptr[-1].item())
-    perm = torch.empty(total, dtype=torch.long, device=score.device)
+    plan = batch_plan(batch, ratio, score.dtype, num_graphs)
+    perm = torch.empty(plan.total, dtype=torch.long, device=score.device)
     lib = _lib.load()
-    ws = _workspace(lib.hgv_topk_ws(n), score.device, "topk")
+    segmented = 0 < plan.max_nodes <= 16384 and not global_sort
+    ws = None if segmented else _workspace(lib.hgv_topk_ws(n), score.device, "topk")
     score = score.detach().contiguous().to(torch.float32)
-    _lib.call("hgv_topk_perm", score.data_ptr(), batch.data_ptr(), ptr.data_ptr(), k_g.data_ptr(), kptr.data_ptr(), n,
-              num_graphs, perm.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+    _lib.call("hgv_topk_perm", score.data_ptr(), batch.data_ptr(), plan.ptr.data_ptr(), plan.k.data_ptr(),
+              plan.kptr.data_ptr(), n, plan.num_graphs, plan.max_nodes if segmented else 0, perm.data_ptr(), _lib.ptr(ws),
+              ws.numel() if ws is not None else 0, _lib.stream())
     return perm
+
+
+_bounded_pooling = False
+
+
+@contextlib.contextmanager
+def bounded_pooling(enabled: bool = True):
+    """Inside this context ``filter_adj`` does not read the number of surviving edges back to the host: it returns
+    the coarse ``edge_index`` at its capacity ``[2, E]`` (surviving edges first, in order; the rest zeros) with the
+    device-side count attached as ``.hgv_count``.  For callers that discard or only forward the pooled graph (the
+    reference's train loops do, autoencoder/vae_with_pool.py:154): no host synchronisation, so the step can be
+    captured into a HIP graph."""
+    global _bounded_pooling
+    prev, _bounded_pooling = _bounded_pooling, bool(enabled)
+    try:
+        yield
+    finally:
+        _bounded_pooling = prev
 
 
 def filter_adj(edge_index: torch.Tensor, edge_attr, perm: torch.Tensor, num_nodes: int):
@@ -851,6 +902,7 @@ def filter_adj(edge_index: torch.Tensor, edge_attr, perm: torch.Tensor, num_node
     _lib.require_cuda(edge_index, perm)
     e = edge_index.size(1)
     dev = edge_index.device
+    bounded = _bounded_pooling
     out = torch.empty(2, max(e, 1), dtype=torch.long, device=dev)
     kept = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -858,11 +910,45 @@ def filter_adj(edge_index: torch.Tensor, edge_attr, perm: torch.Tensor, num_node
     ws = _workspace(lib.hgv_filter_adj_ws(e, num_nodes), dev, "filter_adj")
     _lib.call("hgv_filter_adj", edge_index.data_ptr(), edge_index.stride(0), edge_index.stride(1), e, num_nodes,
               perm.data_ptr(), perm.numel(), out.data_ptr(), out.stride(0), kept.data_ptr(), count.data_ptr(),
-              ws.data_ptr(), ws.numel(), _lib.stream())
+              1 if bounded else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+    if bounded:
+        ei = out[:, :e]
+        ei.hgv_count = count
+        ea = edge_attr.index_select(0, kept[:e].long()) if edge_attr is not None else None
+        return ei, ea
     m = int(count.item())  # the output size is data-dependent: one host sync, as in PyG
     ei = out[:, :m]
     ea = edge_attr.index_select(0, kept[:m].long()) if edge_attr is not None else None
     return ei, ea
+
+
+class _GcnAggregate(torch.autograd.Function):
+    """out_i = dis_i * sum_{j -> i} dis_j * h_j  (the symmetric normalisation of GCNConv as neighbour / row weights of
+    the aggregation kernel; backward = the same reduction over the transposed CSR)."""
+
+    @staticmethod
+    def forward(ctx, h, graph: Graph, dis):
+        h = as_padded(h)
+        out = new_padded(graph.num_nodes, h.size(1), h.device, zero_pad=False)
+        _agg_launch(graph.by_dst, graph.num_nodes, h, h.size(1), 2, dis, None, dis, None, out)
+        ctx.graph = graph
+        ctx.save_for_backward(dis)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dis,) = ctx.saved_tensors
+        graph = ctx.graph
+        g = as_padded(g)
+        gh = new_padded(graph.num_nodes, g.size(1), g.device, zero_pad=False)
+        _agg_launch(graph.by_src, graph.num_nodes, g, g.size(1), 2, dis, None, dis, None, gh)
+        return gh, None, None
+
+
+def gcn_aggregate(h: torch.Tensor, loop_graph: Graph) -> torch.Tensor:
+    """D^-1/2 (A + I) D^-1/2 h over the loop-augmented graph (degrees over targets, self loops included)."""
+    _lib.require_cuda(h)
+    return _GcnAggregate.apply(h, loop_graph, loop_graph.gcn_dis)
 
 
 class _GatherScale(torch.autograd.Function):

@@ -145,6 +145,15 @@ class Graph:
         return self._inv_deg
 
     @property
+    def gcn_dis(self) -> torch.Tensor:
+        """in-degree^-1/2 as fp32 [N] (0 for isolated targets): GCNConv's symmetric normalisation, meant for the
+        loop-augmented graph where every degree is >= 1."""
+        if getattr(self, "_gcn_dis", None) is None:
+            d = self.in_degree.to(torch.float32).pow(-0.5)
+            self._gcn_dis = torch.where(torch.isinf(d), torch.zeros_like(d), d)
+        return self._gcn_dis
+
+    @property
     def src_pos_to_dst_pos(self) -> torch.Tensor:
         """For each position of the by-source CSR, the position of the same edge in the by-target CSR."""
         if self._t2f is None:

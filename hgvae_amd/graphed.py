@@ -7,8 +7,9 @@ a few microseconds and the host launch path dominates.  ``GraphedTrainStep`` rec
 graph on a side stream and replays it; dropout masks and normal draws stay fresh on every replay
 because the kernels add a device-side step counter to their Philox offsets.
 
-The pooling variants synchronise with the host (data-dependent output sizes) and cannot be
-captured; they keep running eagerly.
+The pooling variants are capturable as well: inside their loss functions the coarse graph stays at
+its capacity (``functional.bounded_pooling``: no read-back of the surviving edge count), and the sizes
+that depend only on the batch vector are cached per batch tensor during the warm-up.
 """
 from __future__ import annotations
 

@@ -232,7 +232,9 @@ class PoolVAE(_VAEBase):
     def decode(self, z, x1):
         d1 = self.decoder1
         h = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=True)
-        return Fn.dual_linear(h + x1, self.decoder2[0].weight, None, None, self.decoder2[0].bias)
+        # (h + x1) W^T as one K-concatenated product h W^T + x1 W^T: the sum is never written
+        w = self.decoder2[0].weight
+        return Fn.dual_linear(h, w, x1, w, self.decoder2[0].bias)
 
     def forward(self, x, edge_index, batch):
         x1, mean, log_std = self.encode(x, edge_index)
@@ -334,7 +336,8 @@ def train_vae_custom_pool(model, loader, optimizer, clip_value=None, device=None
 
 
 def custom_pool_step_loss(model, x, edge_index, batch):
-    reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
+    with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
+        reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
     recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
     return recon_loss + model.beta * model.kl_divergence(mean, log_std)
 
@@ -373,7 +376,8 @@ def train_vae(model, loader, optimizer, lambda_kl=1.0):
 def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     """Loss of one reference train step (no backward)."""
     share = getattr(model, "share_first_conv", None)
-    with share() if share is not None else contextlib.nullcontext():
+    # the loss looks at the reconstruction only: pooled graphs (pool variants) may stay at their capacity
+    with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling():
         out = model(x, edge_index, batch)
         enc = model.encode(x, edge_index)
     mean, log_std = enc[-2], enc[-1]

@@ -180,18 +180,21 @@ int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, 
 /* ---- SAGPooling: autoencoder/vae_with_pool.py:25,36,39 and :42-50;
  *      autoencoder/vae_custom_pool.py:56-58 ------------------------------------------------
  * hgv_topk_perm: per graph (ascending graph id) the k[g] highest-scoring nodes, descending score,
- * ties by ascending node id.  batch [N], ptr [B+1], k [B], kptr [B+1] are int64 device arrays. */
+ * ties by ascending node id.  batch [N], ptr [B+1], k [B], kptr [B+1] are int64 device arrays.  max_nodes: node count
+ * of the largest graph when the caller knows it (<= 0: unknown); when it is <= 16384 every graph is sorted by one
+ * workgroup in LDS (one launch, ws unused), otherwise global radix-sort passes over all N scores run. */
 size_t hgv_topk_ws(int64_t N);
 int hgv_topk_perm(const float* score, const int64_t* batch, const int64_t* ptr, const int64_t* k,
-                  const int64_t* kptr, int64_t N, int64_t B, int64_t* perm, void* ws, size_t ws_bytes,
+                  const int64_t* kptr, int64_t N, int64_t B, int64_t max_nodes, int64_t* perm, void* ws, size_t ws_bytes,
                   hgv_stream_t stream);
 /* filter_adj: keep edges with both ends in perm, relabel to positions in perm, original order.
  * out_ei: [2, cap] int64 (row stride ld_out, cap >= E suffices); kept_ids (nullable): original
- * edge id of every kept edge; count[0]: number of kept edges. */
+ * edge id of every kept edge; count[0]: number of kept edges.  fill_tail != 0: slots [count, E) of out_ei / kept_ids are
+ * written as zeros, so the whole capacity holds valid indices (for callers that do not read count back). */
 size_t hgv_filter_adj_ws(int64_t E, int64_t N);
 int hgv_filter_adj(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int64_t E, int64_t N,
                    const int64_t* perm, int64_t K, int64_t* out_ei, int64_t ld_out, int32_t* kept_ids,
-                   int32_t* count, void* ws, size_t ws_bytes, hgv_stream_t stream);
+                   int32_t* count, int fill_tail, void* ws, size_t ws_bytes, hgv_stream_t stream);
 /* out[q,:] = x[idx[q],:] * (scale ? scale[idx[q]] : 1)   (x[perm] * score[perm], x[perm]) */
 int hgv_gather_rows(const float* x, int64_t ldx, const int64_t* idx, const float* scale, int64_t K, int F,
                     float* out, int64_t ldo, hgv_stream_t stream);

@@ -357,10 +357,25 @@ def test_topk_perm_matches_oracle_with_ties():
     score[10:40] = score[10]        # ties inside a graph
     score[500:520] = 0.0
     score[520:530] = -0.0           # signed zeros compare equal
+    bd = batch.to(dev())
     for ratio in (0.5, 0.3, 1.0):
         ref = O.topk(score, ratio, batch)
-        perm = Fn.topk_perm(score.to(dev()), ratio, batch.to(dev()))
-        assert torch.equal(perm.cpu(), ref), ratio
+        for global_sort in (False, True):          # one workgroup per graph in LDS / radix passes over all scores
+            perm = Fn.topk_perm(score.to(dev()), ratio, bd, global_sort=global_sort)
+            assert torch.equal(perm.cpu(), ref), (ratio, global_sort)
+
+
+def test_topk_perm_graph_sizes_around_the_lds_table():
+    """Power-of-two boundaries of the in-LDS sort, its 16384-node capacity and a graph beyond it (global path)."""
+    from hgvae_amd import functional as Fn
+    gen = torch.Generator().manual_seed(42)
+    for sizes in ([1, 2, 3, 1023, 1024, 1025], [16384, 5], [15200, 13239], [16385, 40]):
+        batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+        score = torch.tanh(torch.randn(sum(sizes), generator=gen))
+        score[::7] = score[0]                   # many ties
+        ref = O.topk(score, 0.5, batch)
+        perm = Fn.topk_perm(score.to(dev()), 0.5, batch.to(dev()))
+        assert torch.equal(perm.cpu(), ref), sizes
 
 
 def test_filter_adj_and_unpool_bit_exact():
@@ -378,6 +393,13 @@ def test_filter_adj_and_unpool_bit_exact():
     assert torch.equal(out2.cpu(), ref_ei)
     out3, _ = Fn.filter_adj(ei.to(dev()), None, perm[:0].to(dev()), n)
     assert out3.shape == (2, 0)
+    # capacity-bounded mode (no host read-back): kept edges first, zeros behind, count on the device
+    with Fn.bounded_pooling():
+        b_ei, b_ea = Fn.filter_adj(ei.to(dev()), ea.to(dev()), perm.to(dev()), n)
+    m = int(b_ei.hgv_count.item())
+    assert m == ref_ei.size(1) and b_ei.shape == (2, ei.size(1))
+    assert torch.equal(b_ei[:, :m].cpu(), ref_ei) and int(b_ei[:, m:].abs().max()) == 0
+    assert torch.equal(b_ea[:m].cpu(), ref_ea)
     # unpool gathers
     x = torch.randn(n, 138, generator=gen)
     assert torch.equal(Fn.gather_rows(x.to(dev()), perm.to(dev())).cpu(), x[perm])
