@@ -49,6 +49,7 @@ SIGNATURES = {
     "hgv_pack_rows": (C.c_int, [_i32]),
     "hgv_pack_bytes": (_sz, [_i32, _i32]),
     "hgv_pack_weight": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "hgv_pdb_build": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _vp]),
     "hgv_collate_nodes": (C.c_int, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp,
                                     _vp]),
     "hgv_collate_edges": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i64, _vp,

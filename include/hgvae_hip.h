@@ -73,6 +73,18 @@ int hgv_collate_edges(const int64_t* ei_all, int64_t e_total, const int32_t* col
                       const int64_t* out_eptr, int64_t e_out, int64_t max_edges, int64_t* ei_out, int32_t* col_dst_out, int32_t* perm_dst_out,
                       int32_t* col_src_out, int32_t* perm_src_out, float* ea_out, hgv_stream_t stream);
 
+/* ---- graphs from parsed PDB ATOM records, on the device, in the packed shard layout (replaces pdb_to_pyg_data,
+ *      gvae/create_graphs_for_gvae.py:67-144: one-hot(atom name) | one-hot(residue name) | 3 force columns per node, one
+ *      directed edge from every ATOM record to the next of its file, edge attribute = float32 of the float64 distance) ----
+ * atom_idx / res_idx [Nt] int32 category numbers, forces [Nt, 3] (nullable: zeros), coords [Nt, 3] float64 (nullable when
+ * ea is null), node_ptr / edge_ptr [G+1] int64 device arrays (a graph of n nodes has n - 1 edges), max_edges = the largest
+ * edge count of a graph.  x [Nt, ldx]: 16-byte aligned, ldx a multiple of 4 >= n_atom + n_res + 3, pad columns zeroed;
+ * ei [2][Et] union-wide node numbers; ea [Et] (nullable).  status (nullable, caller-zeroed) is set to 1 if a category
+ * number was outside its range (it is clamped). */
+int hgv_pdb_build(const int32_t* atom_idx, const int32_t* res_idx, const float* forces, const double* coords,
+                  const int64_t* node_ptr, const int64_t* edge_ptr, int G, int64_t Nt, int64_t Et, int64_t max_edges,
+                  int n_atom, int n_res, float* x, int64_t ldx, int64_t* ei, float* ea, int32_t* status, hgv_stream_t stream);
+
 /* Stable LSD radix sort of (uint32 key, int32 value) pairs on key bits [bit_lo, bit_hi).
  * vals_in may be null (values = positions).  Used by the per-graph top-k of SAGPooling
  * (autoencoder/vae_with_pool.py:39). */
