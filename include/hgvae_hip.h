@@ -286,6 +286,12 @@ int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t l
                   const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
                   void* ws, size_t ws_bytes, hgv_stream_t stream);
 
+/* ---- clustering export: pairwise distances of the atoms of one structure (scipy.spatial.distance_matrix at
+ *      gvae/gvae_skipcon.py:352-354, float64) ----------------------------------------------------------------------
+ * coords [n, dim] float64 (dim 1..4, contiguous) -> out [n, n] float64 with leading dimension ld >= n; rowsum [n]
+ * (nullable) receives the row sums of the matrix (= its column sums: what the PCA step centres with). */
+int hgv_distance_matrix(const double* coords, int64_t n, int dim, double* out, int64_t ld, double* rowsum, hgv_stream_t stream);
+
 /* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
  *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------
  * hgv_adam_step: torch's Adam arithmetic (bias-corrected, eps added after the sqrt(v)/sqrt(1-b2^t) division,
