@@ -307,10 +307,22 @@ __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs
 // ---------------- backward ----------------
 struct BwdArgs {
     const float* g; int64_t ldg;
+    const float* g2; int64_t ldg2;   // optional second incoming gradient (the output had two consumers): g + g2 is used
     const float* mean; const float* rstd; const float* gamma;
     const float* sums;   // [2][Hp]: sum g, sum g*xhat (apply pass only)
     float* dy; int64_t lddy;
 };
+
+// incoming gradient chunk: g (+ g2 when the forward output fed two consumers)
+template <bool VEC>
+__device__ __forceinline__ float4 ldg4(const BwdArgs& b, int64_t row, int c0, int H) {
+    float4 v = ld4<VEC>(b.g, b.ldg, row, c0, H);
+    if (b.g2) {
+        const float4 w = ld4<VEC>(b.g2, b.ldg2, row, c0, H);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    return v;
+}
 
 // partial layout: [block][2][Hp] = (sum g, sum g*xhat)
 template <bool VEC>
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
             float4 yv[2], gv[2], d[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-            gv[0] = ld4<VEC>(b.g, b.ldg, row, cc[0], a.H); gv[1] = ld4<VEC>(b.g, b.ldg, row, cc[1], a.H);
+            gv[0] = ldg4<VEC>(b, row, cc[0], a.H); gv[1] = ldg4<VEC>(b, row, cc[1], a.H);
             apply_d2(a, row, cp, yv, d);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(256) void k_ep_bwd_apply(const EpArgs a, const BwdA
     for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
         float4 d[2], y[2], k[2], gv[2];
         y[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); y[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-        gv[0] = ld4<VEC>(b.g, b.ldg, row, cc[0], a.H); gv[1] = ld4<VEC>(b.g, b.ldg, row, cc[1], a.H);
+        gv[0] = ldg4<VEC>(b, row, cc[0], a.H); gv[1] = ldg4<VEC>(b, row, cc[1], a.H);
         apply_d2(a, row, cp, y, d, k);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -593,8 +605,9 @@ extern "C" int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, in
 }
 
 // Backward of the training-mode forward: dy (w.r.t. the pre-activation), dgamma, dbeta
-// (accumulate != 0: added to dgamma / dbeta, i.e. straight into existing .grad buffers).
-extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu,
+// (accumulate != 0: added to dgamma / dbeta, i.e. straight into existing .grad buffers).  g2 (nullable): a second
+// incoming gradient of the same shape, summed with g on the fly (an output with two consumers).
+extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* y, int64_t ldy, int64_t N, int H, int relu,
                               float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
                               const uint64_t* offset_dev, const float* gamma,
                               const float* save_mean, const float* save_rstd, float* dy, int64_t lddy,
@@ -603,13 +616,13 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64
     EpArgs a; int nb;
     int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
-    HGV_REQUIRE(g && ldg >= H && dy && lddy >= H && save_mean && save_rstd && ws, HGV_EINVAL, "bn_act_bwd: null/short buffer");
+    HGV_REQUIRE(g && ldg >= H && dy && lddy >= H && save_mean && save_rstd && ws && (!g2 || ldg2 >= H), HGV_EINVAL, "bn_act_bwd: null/short buffer");
     HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd: workspace too small or misaligned");
     const int Hp = a.CH * 4;
     float* partial = (float*)ws;
     float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
-    BwdArgs b{g, ldg, save_mean, save_rstd, gamma, sums, dy, lddy};
-    const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(dy, lddy, Hp);
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy};
+    const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(dy, lddy, Hp);
     if (vec) hipLaunchKernelGGL(k_ep_bwd_stats<true>, dim3(nb), dim3(256), 0, stream, a, b, partial);
     else hipLaunchKernelGGL(k_ep_bwd_stats<false>, dim3(nb), dim3(256), 0, stream, a, b, partial);
     hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate);

@@ -601,9 +601,13 @@ def dual_linear(xa, wa, xb=None, wb=None, bias=None):
 # (relu) -> dropout -> batch norm
 # --------------------------------------------------------------------------------------
 class _BnAct(torch.autograd.Function):
+    """(relu) -> dropout -> batch norm.  With ``fork`` the output comes back twice (two handles on one buffer) for a
+    tensor with two consumers, and the backward pass takes both incoming gradients: the kernels add them on the fly,
+    so the sum is never written (autograd alone would add them into a dense tensor with one more pass over memory)."""
+
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum,
-                tracked=None):
+                tracked=None, fork=False):
         _lib.require_cuda(y)
         y = rowmajor(y)
         n, h = y.shape
@@ -622,36 +626,49 @@ class _BnAct(torch.autograd.Function):
                   ld_of(out), ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (relu, p, seed, offset, ctr)
         ctx.save_for_backward(y, gamma, save_mean, save_rstd, mask, beta)
+        if fork:
+            ctx.set_materialize_grads(False)
+            return out, out.view_as(out)
         return out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g2=None):
         y, gamma, save_mean, save_rstd, mask, beta = ctx.saved_tensors
         relu, p, seed, offset, ctr = ctx.cfg
-        g = rowmajor(g)
+        if g is None:
+            g, g2 = g2, None
         n, h = y.shape
+        if g is None:
+            return (None,) * 15
+        g = rowmajor(g)
+        g2 = rowmajor(g2) if g2 is not None else None
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
-        dy = new_padded(n, h, y.device, zero_pad=not (is_vec4(y) and is_vec4(g)))
+        vec = is_vec4(y) and is_vec4(g) and (g2 is None or is_vec4(g2))
+        dy = new_padded(n, h, y.device, zero_pad=not vec)
         need = ctx.needs_input_grad
         # affine gradients: straight into the parameters' .grad buffers when that mode is on
         gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
         direct = gbuf is not None and bbuf is not None
         dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=y.device)
         dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=y.device)
-        _lib.call("hgv_bn_act_bwd", g.data_ptr(), ld_of(g), y.data_ptr(), ld_of(y), n, h, int(relu), float(p),
+        _lib.call("hgv_bn_act_bwd", g.data_ptr(), ld_of(g), _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, y.data_ptr(),
+                  ld_of(y), n, h, int(relu), float(p),
                   _lib.ptr(mask), seed, offset, ctr, _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
                   dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(),
                   ws.numel(), _lib.stream())
         if direct:
             dgamma = dbeta = None
-        return (dy, dgamma if need[1] else None, dbeta if need[2] else None,
-                None, None, None, None, None, None, None, None, None, None, None)
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 12
 
 
-def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool) -> torch.Tensor:
-    """relu? -> Dropout(p) -> BatchNorm1d, fused.  ``bn`` supplies affine parameters and running buffers."""
+def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
+    """relu? -> Dropout(p) -> BatchNorm1d, fused.  ``bn`` supplies affine parameters and running buffers.  With ``fork``
+    the result is returned as a pair of handles for its two consumers (see :class:`_BnAct`)."""
     _lib.require_cuda(y)
+    if fork and not (training and torch.is_grad_enabled() and y.requires_grad):
+        out = bn_act(y, bn, relu, p, training)
+        return out, out
     if not training:
         y = rowmajor(y)
         out = new_padded(y.size(0), y.size(1), y.device, zero_pad=not is_vec4(y))
@@ -665,7 +682,7 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
     momentum = bn.momentum if bn.momentum is not None else 0.1
     # num_batches_tracked is incremented by the statistics kernel
     return _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, ctr,
-                        bn.eps, momentum, bn.num_batches_tracked)
+                        bn.eps, momentum, bn.num_batches_tracked, fork)
 
 
 # --------------------------------------------------------------------------------------

@@ -66,12 +66,12 @@ class _VAEBase(nn.Module):
     n_samples: int
 
     # one encoder/decoder level: conv-or-linear output -> (relu) -> dropout -> batch norm
-    def _finish(self, y, dropout: Optional[nn.Dropout], bn: nn.BatchNorm1d, relu: bool):
+    def _finish(self, y, dropout: Optional[nn.Dropout], bn: nn.BatchNorm1d, relu: bool, fork: bool = False):
         p = dropout.p if dropout is not None else 0.0
-        return Fn.bn_act(y, bn, relu, p, self.training)
+        return Fn.bn_act(y, bn, relu, p, self.training, fork=fork)
 
-    def _sage_level(self, seq, x, g):
-        return self._finish(seq[0](x, g), seq[1], seq[2], relu=True)
+    def _sage_level(self, seq, x, g, fork: bool = False):
+        return self._finish(seq[0](x, g), seq[1], seq[2], relu=True, fork=fork)
 
     def reparameterize(self, mean, log_std):
         ml = join_head(mean, log_std)
@@ -134,14 +134,15 @@ class SkipconVAE(_VAEBase):
         return nn.Sequential(SAGEConv(h, h), nn.Dropout(p), nn.BatchNorm1d(h))
 
     def _level2(self, x1, g):
-        return self._sage_level(self.encoder2, x1, g)
+        return self._sage_level(self.encoder2, x1, g, fork=True)
 
     def encode(self, x, edge_index):
         g = graph_of(edge_index, x.size(0))
         x = padded_input(x)
-        # x1 / x2 feed the next level and, as skips, the decoder: explicit forks keep their summed gradients padded
-        x1, skip1 = Fn.fork(self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True))
-        x2, skip2 = Fn.fork(self._level2(x1, g))
+        # x1 / x2 feed the next level and, as skips, the decoder: the level's epilogue hands out two handles and its
+        # backward pass adds the two incoming gradients inside the kernels
+        x1, skip1 = self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True, fork=True)
+        x2, skip2 = self._level2(x1, g)
         x3 = self._sage_level(self.encoder3, x2, g)
         mean, log_std = split_head(self.encoder3[3](x3, g), self.out_channels)
         return skip1, skip2, mean, log_std
@@ -173,7 +174,7 @@ class SkipconAttentionVAE(SkipconVAE):
         return nn.Sequential(GATConv(h, h, heads=self.heads, dropout=p), nn.BatchNorm1d(h * self.heads))
 
     def _level2(self, x1, g):
-        return self._finish(self.encoder2[0](x1, g), None, self.encoder2[1], relu=True)
+        return self._finish(self.encoder2[0](x1, g), None, self.encoder2[1], relu=True, fork=True)
 
 
 class PoolGraph(nn.Module):

@@ -114,7 +114,9 @@ int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, c
  * y is the pre-activation [N, H].  Dropout keep mask: explicit uint8 [N,H] (contiguous), or
  * Philox4x32-7 (16 random bits per element) keyed by (seed, offset) when mask is null and p > 0; offset_dev (nullable) is a device
  * word added to offset, so a captured graph can draw fresh noise on every replay.  Biased batch variance
- * for normalisation, unbiased for the running update (torch.nn.BatchNorm1d semantics). */
+ * for normalisation, unbiased for the running update (torch.nn.BatchNorm1d semantics).  hgv_bn_act_bwd takes an optional
+ * second incoming gradient g2 (nullable; summed with g on the fly) for outputs that fed two consumers - in the reference
+ * every encoder level's output goes to the next level and, as a skip tensor, to the decoder (gvae/gvae_skipcon.py:119-133). */
 size_t hgv_bn_act_ws(int64_t N, int H);
 int hgv_bn_act_fwd(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask,
                    uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
@@ -136,7 +138,7 @@ int hgv_bn_act_fwd_static(const float* y, int64_t ldy, int64_t N, int H, int rel
 int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, int relu, const float* gamma, const float* beta,
                     float eps, const float* running_mean, const float* running_var, float* out, int64_t ldo,
                     hgv_stream_t stream);
-int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
+int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
                    const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* save_mean,
                    const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, int accumulate,
                    void* ws, size_t ws_bytes, hgv_stream_t stream);
