@@ -41,7 +41,10 @@ struct GatArgs {
     float* out; int64_t ldo;            // forward: out; backward over sources: d xw
     float* row_max; float* row_den;     // per target row: max logit, sum exp + 1e-16
     float* S;                           // per target row: sum_k alpha'_k dad_k
-    float* da;                          // rows kernel: d a_dst; cols kernel: d a_src
+    float* da; int64_t ld_da;           // rows kernel: d a_dst; cols kernel: d a_src (element stride ld_da)
+    const float* da_other;              // cols kernel: d a_dst of the rows kernel (same stride), for the logit projection term
+    const float* att_src; const float* att_dst;   // cols kernel, nullable: a_src = <xw, att_src>, a_dst = <xw, att_dst>; then
+                                        // d xw[j] += d a_src[j] att_src + d a_dst[j] att_dst (the gradient through the logits)
 };
 
 // keep multiplier (0 or 1/(1-p)) of the edge with edge-list position eid
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(128) void k_gat_bwd_rows(const GatArgs a) {
         T2 += al * lk;
     }
     S = grp_sum(S, L); T1 = grp_sum(T1, L); T2 = grp_sum(T2, L);
-    if (lr == 0) { a.S[row] = S; a.da[row] = T1 - S * T2; }
+    if (lr == 0) { a.S[row] = S; a.da[row * a.ld_da] = T1 - S * T2; }
 }
 
 // by-source rows (rowptr / col / perm of the transposed CSR): d xw[j] and d a_src[j]
@@ -268,17 +271,24 @@ __global__ __launch_bounds__(128) void k_gat_bwd_cols(const GatArgs a) {
         dsum += (ap * my_dad - al * Si) * lk;
     }
     dsum = grp_sum(dsum, L);
+    const float dd = a.att_src ? a.da_other[row * a.ld_da] : 0.f;
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
         if (owns[q]) {
             float4 o = acc[q];
+            if (a.att_src) {
+                const float4 s4 = *reinterpret_cast<const float4*>(a.att_src + coff[q]);
+                const float4 d4 = *reinterpret_cast<const float4*>(a.att_dst + coff[q]);
+                o.x += dsum * s4.x + dd * d4.x; o.y += dsum * s4.y + dd * d4.y;
+                o.z += dsum * s4.z + dd * d4.z; o.w += dsum * s4.w + dd * d4.w;
+            }
             if (coff[q] + 1 >= a.C) o.y = 0.f;
             if (coff[q] + 2 >= a.C) o.z = 0.f;
             if (coff[q] + 3 >= a.C) o.w = 0.f;
             *reinterpret_cast<float4*>(a.out + row * a.ldo + coff[q]) = o;
         }
     }
-    if (lr == 0) a.da[row] = dsum;
+    if (lr == 0) a.da[row * a.ld_da] = dsum;
 }
 
 bool vec4_ok(const float* p, int64_t ld, int nchunks) { return p && hgv_aligned(p, 16) && ld % 4 == 0 && ld >= (int64_t)nchunks * 4; }
@@ -349,28 +359,36 @@ extern "C" int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int3
 
 // Backward of hgv_gat_fwd for the output gradient g [N, C]: gxw [N, C] (d xw), da_src [N], da_dst [N].  The by-target
 // CSR (rowptr / col / perm) and the by-source CSR (rowptr_t / col_t / perm_t) of the same edge list, the forward's
-// noise arguments and its row_max / row_den are needed; S [N] is scratch.
+// noise arguments and its row_max / row_den are needed; S [N] is scratch.  da_src / da_dst are written with element stride
+// ld_da (two columns of one [N, ld] matrix).  att_src / att_dst (nullable, [ceil(C/4)*4], 16-byte aligned): when the logits
+// were formed as a_src = <xw, att_src>, a_dst = <xw, att_dst>, the gradient that reaches xw through them
+// (da_src[j] att_src + da_dst[j] att_dst) is added to gxw in the same pass.
 extern "C" int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* rowptr_t,
                            const int32_t* col_t, const int32_t* perm_t, int64_t N, const float* g, int64_t ldg,
                            const float* xw, int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst,
                            int64_t ld_dst, float slope, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
                            const uint64_t* offset_dev, const float* row_max, const float* row_den, float* S, float* gxw,
-                           int64_t ldgx, float* da_src, float* da_dst, hipStream_t stream) {
+                           int64_t ldgx, float* da_src, float* da_dst, int64_t ld_da, const float* att_src,
+                           const float* att_dst, hipStream_t stream) {
     HGV_REQUIRE(N >= 0, HGV_EINVAL, "gat_bwd: negative N");
     if (N == 0) return HGV_OK;
     GatArgs a{}; int cpl;
     int rc = fill_common(a, "gat_bwd", rowptr, col, perm, N, a_src, ld_src, a_dst, ld_dst, slope, p, mask, seed, offset,
                          offset_dev, C, &cpl);
     if (rc != HGV_OK) return rc;
-    HGV_REQUIRE(rowptr_t && col_t && perm_t && row_max && row_den && S && da_src && da_dst, HGV_EINVAL, "gat_bwd: null buffer");
+    HGV_REQUIRE(rowptr_t && col_t && perm_t && row_max && row_den && S && da_src && da_dst && ld_da >= 1, HGV_EINVAL, "gat_bwd: null buffer");
+    HGV_REQUIRE((att_src == nullptr) == (att_dst == nullptr), HGV_EINVAL, "gat_bwd: att_src and att_dst go together");
+    HGV_REQUIRE(!att_src || (hgv_aligned(att_src, 16) && hgv_aligned(att_dst, 16)), HGV_EINVAL,
+                "gat_bwd: att_src / att_dst must be 16-byte aligned vectors padded to ceil(C/4)*4 floats");
     HGV_REQUIRE(vec4_ok(xw, ldx, a.nchunks) && vec4_ok(g, ldg, a.nchunks) && vec4_ok(gxw, ldgx, a.nchunks), HGV_EINVAL,
                 "gat_bwd: g / xw / gxw must be 16-byte aligned with leading dimensions that are multiples of 4 and cover ceil(C/4)*4 columns");
     a.xw = xw; a.ldx = ldx; a.g = g; a.ldg = ldg;
     a.row_max = const_cast<float*>(row_max); a.row_den = const_cast<float*>(row_den); a.S = S;
     const dim3 grid((unsigned)hgv_cdiv(N, 2 * (64 >> a.lshift)));
-    a.da = da_dst;
+    a.da = da_dst; a.ld_da = ld_da;
     HGV_GAT_LAUNCH(k_gat_bwd_rows, cpl, grid, stream, a)
-    a.rowptr = rowptr_t; a.col = col_t; a.perm = perm_t; a.out = gxw; a.ldo = ldgx; a.da = da_src;
+    a.rowptr = rowptr_t; a.col = col_t; a.perm = perm_t; a.out = gxw; a.ldo = ldgx; a.da = da_src; a.da_other = da_dst;
+    a.att_src = att_src; a.att_dst = att_dst;
     HGV_GAT_LAUNCH(k_gat_bwd_cols, cpl, grid, stream, a)
     HGV_CHECK_LAUNCH("gat_bwd");
     return HGV_OK;

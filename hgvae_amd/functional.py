@@ -779,32 +779,38 @@ def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 class _GatAggregate(torch.autograd.Function):
     """out_i = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k] (+ bias)
 
-    over the loop-augmented graph ``lg``.  Inputs xw [N, C], a_src [N], a_dst [N].  One kernel forward,
-    two backward (one per CSR direction); the attention weights are recomputed, never stored.
+    over the loop-augmented graph ``lg`` with the logits a_src = xw att[0], a_dst = xw att[1] (``att`` [2, C]: GATConv's
+    att_src / att_dst).  One projection (both logit columns at once) and one attention kernel forward; backward: one
+    kernel per CSR direction - the attention weights are recomputed, never stored, and the gradient that reaches xw
+    through the logits is added inside the second kernel - plus the [2, C] weight gradient of ``att``.
     """
 
     @staticmethod
-    def forward(ctx, xw, a_src, a_dst, bias, lg: Graph, slope, p, mask, seed, offset, ctr):
-        _lib.require_cuda(xw, a_src, a_dst)
+    def forward(ctx, xw, att, bias, lg: Graph, slope, p, mask, seed, offset, ctr):
+        _lib.require_cuda(xw, att)
         xw = as_padded(xw)
         n, c = lg.num_nodes, xw.size(1)
+        if tuple(att.shape) != (2, c):
+            raise _lib.HgvError(f"attention vectors of shape {tuple(att.shape)} for features of width {c}")
         csr = lg.by_dst
         dev = xw.device
+        ab = _gemm_nt(xw, _image(att, None, False), None, None, 2)            # [N, 2]: a_src | a_dst, leading dimension 4
         row_max = torch.empty(n, dtype=torch.float32, device=dev)
         row_den = torch.empty(n, dtype=torch.float32, device=dev)
         out = new_padded(n, c, dev, zero_pad=False)
+        lda = ld_of(ab)
         _lib.call("hgv_gat_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n, xw.data_ptr(), ld_of(xw),
-                  c, a_src.data_ptr(), a_src.stride(0), a_dst.data_ptr(), a_dst.stride(0), float(slope), float(p),
+                  c, ab.data_ptr(), lda, ab.data_ptr() + 4, lda, float(slope), float(p),
                   _lib.ptr(mask), seed, offset, ctr, _lib.ptr(bias), out.data_ptr(), ld_of(out), row_max.data_ptr(),
                   row_den.data_ptr(), _lib.stream())
         ctx.lg, ctx.cfg = lg, (slope, p, seed, offset, ctr)
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(xw, a_src, a_dst, row_max, row_den, mask)
+        ctx.save_for_backward(xw, att, ab, row_max, row_den, mask)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xw, a_src, a_dst, row_max, row_den, mask = ctx.saved_tensors
+        xw, att, ab, row_max, row_den, mask = ctx.saved_tensors
         lg = ctx.lg
         slope, p, seed, offset, ctr = ctx.cfg
         n, c = lg.num_nodes, xw.size(1)
@@ -812,20 +818,27 @@ class _GatAggregate(torch.autograd.Function):
         csr, csr_t = lg.by_dst, lg.by_src
         dev = xw.device
         scratch = torch.empty(n, dtype=torch.float32, device=dev)
-        da_src = torch.empty(n, dtype=torch.float32, device=dev)
-        da_dst = torch.empty(n, dtype=torch.float32, device=dev)
+        da = new_padded(n, 2, dev)                                     # d a_src | d a_dst
+        att_p = new_padded(2, c, dev)                                  # rows padded to 16 bytes for the kernel's chunk loads
+        att_p.copy_(att.detach())
         gxw = new_padded(n, c, dev, zero_pad=False)
+        lda, ldd = ld_of(ab), ld_of(da)
         _lib.call("hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), csr_t.rowptr.data_ptr(),
                   csr_t.col.data_ptr(), csr_t.perm.data_ptr(), n, g.data_ptr(), ld_of(g), xw.data_ptr(), ld_of(xw), c,
-                  a_src.data_ptr(), a_src.stride(0), a_dst.data_ptr(), a_dst.stride(0), float(slope), float(p),
+                  ab.data_ptr(), lda, ab.data_ptr() + 4, lda, float(slope), float(p),
                   _lib.ptr(mask), seed, offset, ctr, row_max.data_ptr(), row_den.data_ptr(), scratch.data_ptr(),
-                  gxw.data_ptr(), ld_of(gxw), da_src.data_ptr(), da_dst.data_ptr(), _lib.stream())
-        gbias = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return gxw, da_src, da_dst, gbias, None, None, None, None, None, None, None
+                  gxw.data_ptr(), ld_of(gxw), da.data_ptr(), da.data_ptr() + 4, ldd, att_p.data_ptr(),
+                  att_p.data_ptr() + 4 * ld_of(att_p), _lib.stream())
+        gatt = None
+        if ctx.needs_input_grad[1]:
+            gatt, _ = _gemm_tn(da, xw, False)                          # [2, C] = [da_src | da_dst]^T xw
+        gbias = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gxw, gatt, gbias, None, None, None, None, None, None, None
 
 
-def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, training: bool, bias=None):
-    """Attention-weighted neighbour sum of GATConv (+ bias); a_src / a_dst may be strided columns of one [N, 2] table."""
+def gat_aggregate(xw, att, loop_graph: Graph, slope: float, p: float, training: bool, bias=None):
+    """Attention-weighted neighbour sum of GATConv (+ bias) from the projected features ``xw`` [N, C] and the stacked
+    attention vectors ``att`` [2, C] (att_src; att_dst)."""
     mask, seed, offset, ctr = None, 0, 0, None
     if training and p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
@@ -833,9 +846,7 @@ def gat_aggregate(xw, a_src, a_dst, loop_graph: Graph, slope: float, p: float, t
             mask = mask.view(-1)
     else:
         p = 0.0
-    if a_src.dim() != 1 or a_dst.dim() != 1 or a_src.dtype != torch.float32 or a_dst.dtype != torch.float32:
-        raise _lib.HgvError("gat_aggregate: a_src / a_dst must be float32 vectors")
-    return _GatAggregate.apply(xw, a_src, a_dst, bias, loop_graph, slope, p, mask, seed, offset, ctr)
+    return _GatAggregate.apply(xw, att, bias, loop_graph, slope, p, mask, seed, offset, ctr)
 
 
 # --------------------------------------------------------------------------------------

@@ -184,12 +184,16 @@ int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, 
 /* Backward (autograd of the above, loss.backward() gvae/gvae_skipcon_attention.py:181) for the output gradient g [N, C]:
  * gxw [N, C] = d xw, da_src [N], da_dst [N].  Takes both CSRs of the same edge list (rowptr_t / col_t / perm_t = by
  * source), the forward's noise arguments and row_max / row_den; S [N] is scratch.  Two kernels (one per CSR direction),
- * each recomputing the attention weights of its edges; same layout contract as hgv_gat_fwd for g / xw / gxw. */
+ * each recomputing the attention weights of its edges; same layout contract as hgv_gat_fwd for g / xw / gxw.  da_src /
+ * da_dst are written with element stride ld_da.  att_src / att_dst (nullable, padded to ceil(C/4)*4 floats, 16-byte
+ * aligned): if the logits are a_src = <xw, att_src>, a_dst = <xw, att_dst> (GATConv's att parameters), the part of d xw
+ * that flows through them, da_src[j] att_src + da_dst[j] att_dst, is added to gxw in the same pass. */
 int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* rowptr_t, const int32_t* col_t,
                 const int32_t* perm_t, int64_t N, const float* g, int64_t ldg, const float* xw, int64_t ldx, int C,
                 const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
                 const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* row_max,
-                const float* row_den, float* S, float* gxw, int64_t ldgx, float* da_src, float* da_dst, hgv_stream_t stream);
+                const float* row_den, float* S, float* gxw, int64_t ldgx, float* da_src, float* da_dst, int64_t ld_da,
+                const float* att_src, const float* att_dst, hgv_stream_t stream);
 
 /* ---- SAGPooling: autoencoder/vae_with_pool.py:25,36,39 and :42-50;
  *      autoencoder/vae_custom_pool.py:56-58 ------------------------------------------------

@@ -330,8 +330,8 @@ def test_gat_attention_rows_sum_to_one_known_answer():
     from hgvae_amd.graph import Graph
     g = Graph(torch.tensor([[0, 1], [2, 2]], device=dev()), 3).with_self_loops()
     xw = torch.tensor([[1.0, 0.0], [0.0, 1.0], [3.0, 3.0]], device=dev())
-    z = torch.zeros(3, device=dev())
-    out = Fn.gat_aggregate(xw, z, z, g, 0.2, 0.0, False).cpu()
+    att = torch.zeros(2, 2, device=dev())
+    out = Fn.gat_aggregate(xw, att, g, 0.2, 0.0, False).cpu()
     assert torch.allclose(out, torch.tensor([[1.0, 0.0], [0.0, 1.0], [4.0 / 3, 4.0 / 3]]), atol=1e-6)
 
 
