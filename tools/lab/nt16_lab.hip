@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
     const int K1 = argc > 2 ? atoi(argv[2]) : 138, K2 = argc > 3 ? atoi(argv[3]) : 138, N = argc > 4 ? atoi(argv[4]) : 138;
     const char* tag = argc > 5 ? argv[5] : "base";
     const int64_t lda = (K1 + 3) / 4 * 4, ldb = (K2 + 3) / 4 * 4, ldc = (N + 3) / 4 * 4;
-    std::vector<float> h((size_t)M * lda);
+    std::vector<float> h((size_t)M * (lda > ldc ? (lda > ldb ? lda : ldb) : (ldc > ldb ? ldc : ldb)) + 1024);
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
     float *A1, *A2 = nullptr, *W, *C, *bias, *G, *GW1, *GW2;
     hipMalloc(&A1, (size_t)M * lda * 4); hipMemcpy(A1, h.data(), (size_t)M * lda * 4, hipMemcpyHostToDevice);

@@ -1,18 +1,25 @@
 #!/bin/bash
-# Regenerates the evidence kept under profiles/ on a GPU box; outputs land in gpurun_out/refresh/.
+# Regenerates the evidence kept under profiles/ on a GPU box; outputs land in gpurun_out/refresh/ (copy what is to be
+# published into profiles/).  One bench line per workload, a rocprofv3 kernel summary of the headline workloads, the
+# two-rank rehearsal (two ranks share the GPU over gloo when the box has one).
 set -o pipefail
 out=gpurun_out/refresh
-mkdir -p $out
+rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-timeout -k 10 200 python3 bench.py > $out/bench.json 2> $out/bench.err || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 bench.py --cpu-sample-graphs 0 > $out/bench_under_rocprof.json 2> $out/kt.err || exit 1
-for p in bf16x6 fp32; do
-  HGVAE_PROJECTION=$p timeout -k 10 120 python3 tools/gemm_probe.py > $out/gemm_probe_$p.txt 2>/dev/null || exit 1
+for w in protein256 protein32 large chig32 attention attention32 pool custom_pool; do
+  timeout -k 10 300 python3 bench.py --workload $w > $out/bench_$w.json 2> $out/bench_$w.err || exit 1
+  echo "bench $w done"
 done
-HGVAE_PROJECTION=bf16x6 timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d $out/pmc -o pmc --output-format csv -- python3 tools/gemm_probe.py > $out/pmc.log 2>&1 || exit 1
-f=$(find $out/pmc -name '*counter_collection.csv' | head -1)
-python3 tools/pmc_kernels.py "$f" k_gemm > $out/gemm_pmc.txt || exit 1
-find $out/kt -name '*kernel_stats.csv' -exec cp {} $out/kernel_stats.csv \;
-rm -rf $out/kt/*/*kernel_trace.csv $out/pmc
-cat $out/bench.json | cut -c1-300
-cat $out/gemm_probe_bf16x6.txt
+for w in chig32 attention pool custom_pool; do
+  timeout -k 10 300 python3 bench.py --workload $w --graph --no-cpu-baseline > $out/bench_${w}_graph.json 2> $out/bench_${w}_graph.err || exit 1
+  echo "bench $w --graph done"
+done
+timeout -k 10 300 python3 bench.py --gpus 2 --workload protein32 --steps 10 --warmup 3 > $out/bench_protein32_2ranks.json 2> $out/bench_protein32_2ranks.err || exit 1
+echo "2-rank rehearsal done"
+for w in protein32 protein256 attention32 pool; do
+  d=$out/kt_$w; mkdir -p $d
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $d -o kt --output-format csv -- python3 bench.py --workload $w --steps 6 --warmup 3 --no-cpu-baseline > $d/bench.json 2> $d/err.log || exit 1
+  python3 tools/step_profile.py $d/kt_kernel_trace.csv 60 $d/seq.txt > $d/summary.txt || exit 1
+  rm -f $d/kt_kernel_trace.csv
+  echo "kernel trace $w done"
+done
