@@ -150,7 +150,14 @@ struct Nt16Args {
     float* C; int64_t ldc; int64_t M;
     int64_t ntiles;            // 16-row tiles
     int wgs0;                  // two-part launches: workgroups [0, wgs0) work on part 0, the rest on part 1
+    int paced;                 // two-part launches: twin waves of the two parts start every row tile together
 };
+
+// Progress counters of paced two-part launches: [part][workgroup][wave] = row tiles whose loads have begun.  They are
+// hints only (a stale or missing value costs time, never correctness), so launches may share them.
+constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
+constexpr int64_t PACE_MIN_BYTES = (int64_t)256 << 20;
+__device__ int pace_ctr[2 * PACE_WGS * PACE_WAVES];
 
 // waves per workgroup: 16 while the registers allow 4 waves per SIMD (<= 128 VGPRs), 12 for the widest parts
 template <int NT> constexpr int nt16_waves() { return NT > 6 ? 12 : 16; }
@@ -207,6 +214,33 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
     // per-lane LDS byte offset of (row i, swizzled piece kq) inside a piece image
     const int wlane = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
 
+    // Paced launches: workgroup r of part 0 and workgroup r of part 1 sit on the same XCD and their waves walk the
+    // same row tiles.  Every wave publishes how many load groups it has issued and lets its twin be at most PACE_AHEAD
+    // groups behind, so the second of the two reads of every A line finds it in the XCD's L2 instead of fetching it from
+    // memory again.  The twin's counter is read two steps before it is looked at (by then the wave waits for older
+    // loads anyway), so the wave that is behind never waits for it; the one that is ahead polls.  A twin that does
+    // not catch up within PACE_SPINS polls (not resident, other XCD) switches this wave's pacing off for the launch.
+    int* pace_mine = pace_ctr + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    const int* pace_twin = pace_ctr + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    bool pace = a.paced != 0;
+    int pace_step = 0;                                // load groups issued by this wave
+    int pace_seen[RING];                              // the twin's counter as read by the last RING load groups (slot = ring slot)
+#pragma unroll
+    for (int d = 0; d < RING; ++d) pace_seen[d] = 0;
+    auto pace_gate = [&](int d) __attribute__((always_inline)) {
+        if (lane == 0) __hip_atomic_store(pace_mine, pace_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(pace_seen[(d + RING - 2) % RING]) < pace_step - (PACE_AHEAD + 2)) {
+            for (int spin = 0;; ++spin) {
+                const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= pace_step - PACE_AHEAD) break;
+                if (spin >= PACE_SPINS) { pace = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        pace_seen[d] = __hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++pace_step;
+    };
+
     // load cursor
     int64_t ltile = gw, lidx = 0; int lq = 0;
     const char *lp1, *lp2;
@@ -218,6 +252,7 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
     f32x4 ring[RING][2];
     int4 e_next = tab[kq];                   // table entry of the load cursor, read one step early
     auto issue = [&](int d) __attribute__((always_inline)) {
+        if (pace) pace_gate(d);
         const int4 e = e_next;
         const char* p = e.z ? lp2 : lp1;
         ring[d][0] = *reinterpret_cast<const f32x4*>(p + e.x);
@@ -334,6 +369,8 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
             }
         }
     }
+    // done: a twin that issues a few more load groups (other ring depth) must not wait for this wave
+    if (a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // One part per launch (the whole weight, or one part of a weight split along N).
@@ -558,7 +595,14 @@ int launch_nt16_pair(Nt16Args a, size_t lds, hipStream_t st) {
     // n tiles, i.e. ~ 11 + NT), so the split that minimises the slower part is near even and is
     // decided by the rounding of the rounds.  Ties go to the split closest to even.
     int share0 = cus / 2;
-    {
+    // Rows that no longer stay in the memory-side cache between the two parts' reads: pace the parts so that the
+    // second read hits L2 (needs the same walk over the row tiles in both parts, i.e. an even split, and twins on
+    // one XCD: workgroups r and r + wgs0 with wgs0 a multiple of 8).
+    const int64_t a_bytes = a.M * 4 * (a.lda1 + (a.A2 ? a.lda2 : 0));
+    const bool paced = a_bytes >= PACE_MIN_BYTES && cus % 16 == 0 && cus / 2 <= PACE_WGS && wpb <= PACE_WAVES &&
+                       hgv_cdiv(a.ntiles, wpb) >= cus / 2 && a.ntiles < ((int64_t)1 << 31);
+    a.paced = paced ? 1 : 0;
+    if (!paced) {
         int64_t best = -1;
         for (int s0 = cus / 4 > 0 ? cus / 4 : 1; s0 <= cus - (cus / 4 > 0 ? cus / 4 : 1) && s0 < cus; ++s0) {
             const int64_t r0 = hgv_cdiv(a.ntiles, (int64_t)s0 * wpb), r1 = hgv_cdiv(a.ntiles, (int64_t)(cus - s0) * wpb);

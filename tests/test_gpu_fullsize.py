@@ -85,6 +85,25 @@ def test_projection_products_at_full_size(big, k2):
     assert rel(bias.grad, gout.double().sum(0)) <= 1e-5
 
 
+def test_two_source_product_rows_do_not_depend_on_the_row_count(big):
+    """At this size the two halves of the 138 + 138 -> 138 weight are walked in step by paired workgroups; at a few
+    thousand rows they are not.  A row of the product depends on that row of the inputs only, so slices computed on
+    their own must match the full-size result bit for bit (any ordering effect of the pairing would show here)."""
+    from hgvae_amd import functional as Fn
+    _, _, x, gen = big
+    xb = torch.randn(N, H, device=DEV, generator=gen)
+    wa = torch.randn(H, H, device=DEV, generator=gen) * 0.1
+    wb = torch.randn(H, H, device=DEV, generator=gen) * 0.1
+    bias = torch.randn(H, device=DEV, generator=gen)
+    with torch.no_grad():
+        full = Fn.dual_linear(x, wa, xb, wb, bias)
+        again = Fn.dual_linear(x, wa, xb, wb, bias)
+        assert torch.equal(full, again)
+        for lo, hi in ((0, 5000), (N // 2 - 37, N // 2 + 4099), (N - 3001, N)):
+            part = Fn.dual_linear(x[lo:hi].contiguous(), wa, xb[lo:hi].contiguous(), wb, bias)
+            assert torch.equal(part, full[lo:hi])
+
+
 def test_relu_dropout_batchnorm_at_full_size(big):
     from hgvae_amd import functional as Fn
     from hgvae_amd.noise import NoiseTape, use_noise
