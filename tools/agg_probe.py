@@ -27,7 +27,7 @@ def main():
     from hgvae_amd import functional as Fn
     from hgvae_amd.graph import Graph, new_padded
     dev = torch.device("cuda:0")
-    batch, dims = build_workload(args.workload, 0, dev)
+    batch, _, dims = build_workload(args.workload, 0, 1, dev)
     f = args.width or dims[1]
     n, e = batch.x.size(0), batch.edge_index.size(1)
     g = Graph(batch.edge_index, n)
