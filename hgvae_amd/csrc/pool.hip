@@ -51,7 +51,7 @@ constexpr int SEG_THREADS = 1024;
 
 __global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __restrict__ score, const int64_t* __restrict__ ptr,
                                                               const int64_t* __restrict__ k, const int64_t* __restrict__ kptr,
-                                                              int64_t* __restrict__ perm) {
+                                                              int64_t* __restrict__ perm, const int cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char seg_raw[];
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(seg_raw);
     const int g = blockIdx.x;
@@ -59,6 +59,13 @@ __global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __res
     const int n = (int)(ptr[g + 1] - lo);
     const int kg = (int)k[g];
     if (n <= 0 || kg <= 0) return;
+    if (n > cap) {
+        // the caller's max_nodes was too small for this graph: its table would not fit the LDS that was asked for.
+        // Stay inside memory and inside the graph (valid node ids, arbitrary choice); the contract names this case.
+        const int64_t base = kptr[g];
+        for (int r = threadIdx.x; r < kg; r += SEG_THREADS) perm[base + r] = lo + (r < n ? r : n - 1);
+        return;
+    }
     int m = 1;
     while (m < n) m <<= 1;                 // table size: next power of two, padded with keys that sort last
     for (int i = threadIdx.x; i < m; i += SEG_THREADS) {
@@ -229,7 +236,7 @@ extern "C" int hgv_topk_perm(const float* score, const int64_t* batch, const int
             HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "topk_perm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
             raised[dev] = true;
         }
-        hipLaunchKernelGGL(k_topk_segment, dim3((unsigned)B), dim3(SEG_THREADS), (size_t)m * 8, stream, score, ptr, k, kptr, perm);
+        hipLaunchKernelGGL(k_topk_segment, dim3((unsigned)B), dim3(SEG_THREADS), (size_t)m * 8, stream, score, ptr, k, kptr, perm, m);
         HGV_CHECK_LAUNCH("topk_perm(segmented)");
         return HGV_OK;
     }

@@ -200,7 +200,9 @@ int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, 
  * hgv_topk_perm: per graph (ascending graph id) the k[g] highest-scoring nodes, descending score,
  * ties by ascending node id.  batch [N], ptr [B+1], k [B], kptr [B+1] are int64 device arrays.  max_nodes: node count
  * of the largest graph when the caller knows it (<= 0: unknown); when it is <= 16384 every graph is sorted by one
- * workgroup in LDS (one launch, ws unused), otherwise global radix-sort passes over all N scores run. */
+ * workgroup in LDS (one launch, ws unused), otherwise global radix-sort passes over all N scores run.  A max_nodes
+ * smaller than a graph's real node count is a caller error: that graph's entries of perm then hold valid node ids of
+ * the graph in no particular order (nothing outside the buffers is touched). */
 size_t hgv_topk_ws(int64_t N);
 int hgv_topk_perm(const float* score, const int64_t* batch, const int64_t* ptr, const int64_t* k,
                   const int64_t* kptr, int64_t N, int64_t B, int64_t max_nodes, int64_t* perm, void* ws, size_t ws_bytes,

@@ -378,6 +378,28 @@ def test_topk_perm_graph_sizes_around_the_lds_table():
         assert torch.equal(perm.cpu(), ref), sizes
 
 
+def test_topk_perm_with_an_undersized_max_nodes_stays_inside_the_graph():
+    """The C entry point trusts max_nodes for the size of its LDS table; a caller that understates it must get valid
+    node ids of the right graph (in no particular order) and the other graphs' results untouched."""
+    from hgvae_amd import _lib
+    gen = torch.Generator().manual_seed(44)
+    sizes = [300, 900, 120]
+    n, b = sum(sizes), len(sizes)
+    ptr = torch.tensor([0, 300, 1200, 1320])
+    k = torch.tensor([150, 450, 60])
+    kptr = torch.tensor([0, 150, 600, 660])
+    batch = torch.repeat_interleave(torch.arange(b), torch.tensor(sizes))
+    score = torch.randn(n, generator=gen)
+    ref = O.topk(score, 0.5, batch)
+    d = dev()
+    perm = torch.full((660,), -7, dtype=torch.int64, device=d)
+    args = [t.to(d) for t in (score, batch, ptr, k, kptr)]
+    _lib.call("hgv_topk_perm", *[t.data_ptr() for t in args], n, b, 512, perm.data_ptr(), None, 0, _lib.stream())
+    got = perm.cpu()
+    assert torch.equal(got[:150], ref[:150]) and torch.equal(got[600:], ref[600:])
+    assert int(got[150:600].min()) >= 300 and int(got[150:600].max()) < 1200
+
+
 def test_filter_adj_and_unpool_bit_exact():
     from hgvae_amd import functional as Fn
     gen = torch.Generator().manual_seed(43)
