@@ -253,8 +253,8 @@ class CoarsenGraph(nn.Module):
 
     The reference's pooling class also evaluates two dense-Laplacian Fiedler values per call
     (vae_custom_pool.py:63-76); their difference lands in a tuple slot this wrapper drops, so it
-    never reaches an output.  ``spectral_probe=True`` evaluates it anyway with
-    ``torch.linalg.eigvalsh`` (O(N^3), off by default).
+    never reaches an output.  ``spectral_probe=True`` evaluates it anyway (:mod:`hgvae_amd.spectral`: the dense
+    Laplacian from one device pass, then the library's symmetric eigensolver, O(N^3); off by default).
     """
 
     def __init__(self, num_node_features, alpha=0.5, spectral_probe=False):
@@ -266,14 +266,8 @@ class CoarsenGraph(nn.Module):
     @staticmethod
     def fiedler_value(edge_index, num_nodes):
         """Second-smallest eigenvalue of I - D^-1/2 A D^-1/2, degree over SOURCES (vae_custom_pool.py:19-53)."""
-        dev = edge_index.device
-        deg = torch.zeros(num_nodes, device=dev).scatter_add_(0, edge_index[0], torch.ones(edge_index.size(1), device=dev))
-        dis = deg.pow(-0.5)
-        dis[torch.isinf(dis)] = 0
-        adj = torch.zeros(num_nodes, num_nodes, device=dev)
-        adj.index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.size(1), device=dev), accumulate=True)
-        lap = torch.eye(num_nodes, device=dev) - dis.view(-1, 1) * adj * dis.view(1, -1)
-        return torch.linalg.eigvalsh(lap)[1]
+        from .spectral import fiedler_value
+        return fiedler_value(edge_index, num_nodes)
 
     def forward(self, x, edge_index, batch):
         x_cg, ei_cg, _, _, _, _ = self.pool1(x, edge_index, batch=batch)

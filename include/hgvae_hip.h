@@ -300,6 +300,16 @@ int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t l
  * (nullable) receives the row sums of the matrix (= its column sums: what the PCA step centres with). */
 int hgv_distance_matrix(const double* coords, int64_t n, int dim, double* out, int64_t ld, double* rowsum, hgv_stream_t stream);
 
+/* ---- spectral terms: dense normalised Laplacian L = I - D^-1/2 A D^-1/2 (autoencoder/vae_laplacian.py:24-46, the matrix
+ *      whose eigenvalues l_frequency :170-191 and compute_fiedler_value autoencoder/vae_custom_pool.py:50-53 take) -------------
+ * edge_index int64 with element (0, e) at edge_index[e * ld_col] and (1, e) at edge_index[ld_row + e * ld_col]; A[r][c] counts
+ * the edges r -> c; dis [n] = degree^-1/2 over sources with 0 for isolated nodes (deg.pow(-0.5), inf -> 0).  out [n, ld]
+ * float32, ld >= n, element (r, c) = (r == c) - (dis[r] * A[r][c]) * dis[c] in that rounding order (the reference's two
+ * products with a diagonal matrix); columns >= n are zero.  status (nullable device int32, zeroed by the caller) gets bit 0
+ * when an edge names a node outside [0, n): the reference raises ValueError there, such edges are skipped here.  n <= 65535. */
+int hgv_normalized_laplacian(const int64_t* edge_index, int64_t ld_row, int64_t ld_col, int64_t E, int64_t n, const float* dis,
+                             float* out, int64_t ld, int32_t* status, hgv_stream_t stream);
+
 /* ---- optimizer step on flat buffers: torch.optim.Adam (gvae/gvae_skipcon.py:294, autoencoder/vae_with_pool.py:270)
  *      and torch.nn.utils.clip_grad_norm_ (autoencoder/vae_custom_pool.py:228-229) ------------------------------
  * hgv_adam_step: torch's Adam arithmetic (bias-corrected, eps added after the sqrt(v)/sqrt(1-b2^t) division,

@@ -159,3 +159,23 @@ def test_oracle_reproduces_golden(tag):
             continue
         got = p.grad.numpy() if p.numel() <= 4096 else summarize_tensor(p.grad)
         assert np.allclose(got, g[key], rtol=1e-5, atol=1e-7), name
+
+
+def test_spectral_restatement_known_answers():
+    """Normalised Laplacian of an undirected cycle: 1 on the diagonal, -1/2 next to it, eigenvalues 1 - cos(2 pi k / n);
+    the reference's one-eigenvalue l_frequency is 0 / 0."""
+    import math
+    from oracle import spectral as OS
+    n = 12
+    a = torch.arange(n)
+    ei = torch.cat([torch.stack([a, (a + 1) % n]), torch.stack([(a + 1) % n, a])], dim=1)
+    lap = OS.normalized_laplacian(ei, n)
+    want = torch.eye(n)
+    want[a, (a + 1) % n] = -0.5
+    want[(a + 1) % n, a] = -0.5
+    assert torch.allclose(lap, want, atol=1e-7)
+    assert abs(float(OS.compute_fiedler_value(ei, n)) - (1 - math.cos(2 * math.pi / n))) < 1e-6
+    assert math.isnan(float(OS.l_frequency(ei, ei, n, n)))
+    # a node without out-edges has degree 0 -> scaling 0, its row and column of A D^-1/2 vanish
+    lap = OS.normalized_laplacian(torch.tensor([[0], [1]]), 2)
+    assert torch.equal(lap, torch.eye(2) - torch.tensor([[0.0, 0.0], [0.0, 0.0]]))
