@@ -125,7 +125,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Handle of torch's current stream on the current device (every launch goes there).  The raw accessors skip the
+    Stream object that ``torch.cuda.current_stream()`` builds - ~8 us per call, paid ~150 times per train step."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -30,11 +30,10 @@ def new_padded(rows: int, cols: int, device, zero_pad: bool = True) -> torch.Ten
 
 def ld_of(t: torch.Tensor) -> int:
     """Leading dimension (elements per row) of a 2-D tensor whose rows are unit-stride."""
-    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
-        raise _lib.HgvError(f"expected a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}")
-    if t.size(0) > 1:
-        return t.stride(0)
-    return max(t.stride(0), t.size(1))
+    sh, st = t.shape, t.stride()
+    if len(sh) != 2 or (sh[1] > 1 and st[1] != 1):
+        raise _lib.HgvError(f"expected a row-major 2-D tensor, got shape {tuple(sh)} strides {st}")
+    return st[0] if sh[0] > 1 else max(st[0], sh[1])
 
 
 def rowmajor(t: torch.Tensor) -> torch.Tensor:
@@ -48,7 +47,8 @@ def rowmajor(t: torch.Tensor) -> torch.Tensor:
 
 
 def is_vec4(t: torch.Tensor) -> bool:
-    return t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 and ld_of(t) >= pad4(t.size(1))
+    ld = ld_of(t)
+    return t.data_ptr() % 16 == 0 and ld % 4 == 0 and ld >= pad4(t.size(1))
 
 
 def as_padded(t: torch.Tensor) -> torch.Tensor:
