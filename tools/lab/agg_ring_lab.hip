@@ -1,0 +1,239 @@
+// Stand-alone lab for an LDS-ring variant of the neighbour aggregation against the library's direct-gather kernel
+// (compiled in through -DKSRC=<aggregate.hip>): same CSR, bitwise comparison of the outputs, launch times.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Ihgvae_amd/csrc -Iinclude
+//        -DKSRC='"hgvae_amd/csrc/aggregate.hip"' tools/lab/agg_ring_lab.hip -o tools/bin/agg_ring_lab
+// Run:   agg_ring_lab [rows] [F] [mode]    mode bits: 1 = treat every neighbour as in-window (timing only, wrong sums),
+//                                                      2 = skip the prefetch of the next block's rows (timing only)
+#include KSRC
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <random>
+#include <vector>
+static char g_err[512];
+void hgv_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
+
+namespace {
+
+struct RingArgs {
+    const int32_t* rowptr; const int32_t* col; const float* x; int64_t ldx; int64_t n_rows; int nchunks; int lshift;
+    float* out; int64_t ldo;
+    int halo, cap_mask; int64_t rows_per_wg; int mode;
+    long long* stamps;      // nullable: wall-clock stamps of workgroup 0 (start, after the first fill, per block: after the sums, after the barrier)
+};
+constexpr int RW = 16;      // waves per workgroup
+
+template <int CPL, int NB>
+__device__ __forceinline__ void batch(float4 (&acc)[CPL], const RingArgs& a, const float4* ring, const int (&coff)[CPL], int my_col,
+                                      int j, int L, int64_t win_lo, unsigned win_rows) {
+    float4 v[NB][CPL];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int c = __shfl(my_col, j + u, L);
+        if ((a.mode & 1) || (unsigned)(c - win_lo) < win_rows) {
+            const float4* r = ring + (size_t)(c & a.cap_mask) * a.nchunks;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[u][q] = r[coff[q] >> 2];
+        } else {
+            const float* r = a.x + (int64_t)c * a.ldx;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) v[u][q] = *reinterpret_cast<const float4*>(r + coff[q]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) vadd(acc[q], v[u][q]);
+}
+
+// PRE: rowptr and the first batch of column indices of the next block are loaded while the current one is reduced
+template <int CPL, int NB, bool PRE>
+__global__ __launch_bounds__(64 * RW) void k_ring(const RingArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    float4* ring = reinterpret_cast<float4*>(lds);
+    const int t = threadIdx.x, lane = t & 63;
+    const int L = 1 << a.lshift, lr = lane & (L - 1), sub = lane >> a.lshift;
+    const int rpw = 64 >> a.lshift, R = rpw * RW, nch = a.nchunks;
+    const int64_t wb = (int64_t)hgv_xcd_remap(blockIdx.x, gridDim.x) * a.rows_per_wg;
+    const int64_t we = min(wb + a.rows_per_wg, a.n_rows);
+    if (wb >= we) return;
+    int ns = 0;
+    const bool stamp = a.stamps && blockIdx.x == 0 && t == 64 * RW - 1;
+    if (stamp) a.stamps[ns++] = wall_clock64();
+    const int ring_f4 = (a.cap_mask + 1) * nch;
+    const float4* x4 = reinterpret_cast<const float4*>(a.x);          // flat layout: ldx == 4 nch
+    auto dst_of = [&](int64_t lo, int e) __attribute__((always_inline)) { return (int)(((lo & a.cap_mask) * nch + e) % ring_f4); };
+    {
+        const int64_t lo = max(wb - a.halo, (int64_t)0), hi = min(wb + R + a.halo, a.n_rows);
+        const int total = (int)(hi - lo) * nch;
+        for (int e0 = t; e0 < total; e0 += 4 * 64 * RW) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = x4[lo * nch + min(e0 + u * 64 * RW, total - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 64 * RW < total) ring[dst_of(lo, e0 + u * 64 * RW)] = v[u];
+        }
+    }
+    const unsigned win_rows = (unsigned)(R + 2 * a.halo);
+    const int wrow = (t >> 6) * rpw + sub;                                // row of this lane group inside a block
+    int n_start = 0, n_end = 0, n_col = 0;
+    if (PRE && wb + wrow < we) {
+        n_start = a.rowptr[wb + wrow]; n_end = a.rowptr[wb + wrow + 1];
+        if (n_start + lr < n_end) n_col = a.col[n_start + lr];
+    }
+    __syncthreads();
+    if (stamp) a.stamps[ns++] = wall_clock64();
+    for (int64_t cur = wb; cur < we; cur += R) {
+        const int64_t nlo = min(cur + R + a.halo, a.n_rows), nhi = cur + R < we ? min(cur + 2 * R + a.halo, a.n_rows) : nlo;
+        const int ntotal = (a.mode & 2) ? 0 : (int)(nhi - nlo) * nch;
+        float4 pf[CPL];
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+            if (t + u * 64 * RW < ntotal) pf[u] = x4[nlo * nch + t + u * 64 * RW];
+        const int64_t row = cur + wrow;
+        int start = 0, end = 0, first_col = 0;
+        if (PRE) {
+            start = n_start; end = n_end; first_col = n_col;
+            const int64_t nrow = row + R;
+            n_start = n_end = 0;
+            if (nrow < we) { n_start = a.rowptr[nrow]; n_end = a.rowptr[nrow + 1]; }
+        } else if (row < we) {
+            start = a.rowptr[row]; end = a.rowptr[row + 1];
+        }
+        if (row < we) {
+            const int64_t win_lo = cur - a.halo;
+            bool owns[CPL]; int coff[CPL]; float4 acc[CPL];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                const int c = q * L + lr;
+                owns[q] = c < nch;
+                coff[q] = (owns[q] ? c : nch - 1) * 4;
+                vzero<4>(acc[q]);
+            }
+            for (int base = start; base < end; base += L) {
+                const int k = base + lr;
+                int my_col = 0;
+                if (PRE && base == start) my_col = first_col;
+                else if (k < end) my_col = a.col[k];
+                const int cnt = min(L, end - base);
+                int j = 0;
+                for (; j + NB <= cnt; j += NB) batch<CPL, NB>(acc, a, ring, coff, my_col, j, L, win_lo, win_rows);
+                for (; j < cnt; ++j) batch<CPL, 1>(acc, a, ring, coff, my_col, j, L, win_lo, win_rows);
+            }
+            const int d = end - start;
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+                vdiv(acc[q], (float)(d > 1 ? d : 1));
+                if (owns[q]) *reinterpret_cast<float4*>(a.out + row * a.ldo + coff[q]) = acc[q];
+            }
+        }
+        if (stamp) a.stamps[ns++] = wall_clock64();
+        if (PRE) {                       // the next block's first column indices: rowptr has arrived by now
+            n_col = 0;
+            if (n_start + lr < n_end) n_col = a.col[n_start + lr];
+        }
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+            if (t + u * 64 * RW < ntotal) ring[dst_of(nlo, t + u * 64 * RW)] = pf[u];
+        __syncthreads();
+        if (stamp) a.stamps[ns++] = wall_clock64();
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : 160984;
+    const int F = argc > 2 ? atoi(argv[2]) : 138;
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;
+    const int nch = (F + 3) / 4; const int64_t ld = nch * 4;
+    // chain-local graph: offsets drawn so that ~41 / 57 / 71 / 83 / 92 / 96.5 % of the neighbours lie within 4 / 8 / 16 / 32 / 64 / 128 rows
+    std::mt19937_64 rng(7);
+    std::vector<int32_t> rowptr(N + 1, 0), col;
+    col.reserve(N * 13);
+    const int bound[7] = {4, 8, 16, 32, 64, 128, 0};
+    const double cum[7] = {0.41, 0.57, 0.71, 0.83, 0.92, 0.965, 1.0};
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (int64_t i = 0; i < N; ++i) {
+        const int deg = 6 + (int)(rng() % 13);
+        std::vector<int32_t> nb;
+        for (int k = 0; k < deg; ++k) {
+            const double u = U(rng);
+            int b = 0;
+            while (u > cum[b]) ++b;
+            int64_t c;
+            if (bound[b] == 0) c = (int64_t)(rng() % N);
+            else {
+                const int lo = b ? bound[b - 1] : 0;
+                const int off = lo + 1 + (int)(rng() % (bound[b] - lo));
+                c = i + ((rng() & 1) ? off : -off);
+                if (c < 0 || c >= N) c = (int64_t)(rng() % N);
+            }
+            nb.push_back((int32_t)c);
+        }
+        std::sort(nb.begin(), nb.end());
+        for (int32_t c : nb) col.push_back(c);
+        rowptr[i + 1] = (int32_t)col.size();
+    }
+    const int64_t E = (int64_t)col.size();
+    std::vector<float> hx((size_t)N * ld);
+    for (auto& v : hx) v = (float)((int)(rng() % 2001) - 1000) / 512.f;
+    int32_t *d_rp, *d_col; float *d_x, *d_ref, *d_out;
+    hipMalloc(&d_rp, (N + 1) * 4); hipMalloc(&d_col, E * 4);
+    hipMalloc(&d_x, (size_t)N * ld * 4); hipMalloc(&d_ref, (size_t)N * ld * 4); hipMalloc(&d_out, (size_t)N * ld * 4);
+    hipMemcpy(d_rp, rowptr.data(), (N + 1) * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_col, col.data(), E * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_x, hx.data(), (size_t)N * ld * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](auto&& fn) {
+        float best = 1e9f, sum = 0.f;
+        for (int it = 0; it < 23; ++it) {
+            hipEventRecord(e0, 0); fn(); hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (it >= 3) { sum += ms; best = std::min(best, ms); }
+        }
+        return std::make_pair(sum / 20 * 1e3f, best * 1e3f);
+    };
+    auto direct = [&]() {
+        if (hgv_agg_fwd(d_rp, d_col, N, d_x, ld, F, 1, nullptr, nullptr, nullptr, nullptr, 0, d_ref, ld, 0)) { printf("direct: %s\n", g_err); exit(1); }
+    };
+    const auto td = timeit(direct);
+    // lanes per row / chunks per lane as the library picks them
+    int ls = 6, cpl = 4; { int64_t best = -1; for (int l = 0; l <= 6; ++l) { const int Lc = 1 << l; if (Lc < 8 && Lc < nch) continue; int c = (nch + Lc - 1) / Lc; if (c > 4) continue; if (best < 0 || (int64_t)Lc * c < best) { best = (int64_t)Lc * c; ls = l; cpl = c; } } }
+    const int R = (64 >> ls) * RW;
+    int cap = 1; while ((size_t)(2 * cap) * nch * 16 <= 144 * 1024) cap *= 2;
+    const int halo = (cap - 2 * R) / 2;
+    int64_t grid = std::min<int64_t>(256, (N + 4 * R - 1) / (4 * R));
+    RingArgs a{d_rp, d_col, d_x, ld, N, nch, ls, d_out, ld, halo, cap - 1, ((N + grid - 1) / grid + R - 1) / R * R, mode, nullptr};
+    long long* d_st; hipMalloc(&d_st, 64 * 8); hipMemset(d_st, 0, 64 * 8);
+    grid = (N + a.rows_per_wg - 1) / a.rows_per_wg;
+    const size_t lds = (size_t)cap * nch * 16;
+    printf("N=%lld E=%lld F=%d  lanes/row %d chunks/lane %d  R=%d halo=%d cap=%d  grid=%lld rows/wg=%lld lds=%zu\n", (long long)N,
+           (long long)E, F, 1 << ls, cpl, R, halo, cap, (long long)grid, (long long)a.rows_per_wg, lds);
+    printf("direct            avg %.1f us  best %.1f us\n", td.first, td.second);
+    if (cpl != 3 || halo < 8) { printf("lab covers chunks/lane = 3 only\n"); return 0; }
+    auto run = [&](const char* name, auto kern) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        hipMemset(d_out, 0, (size_t)N * ld * 4);
+        const auto tr = timeit([&]() { hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * RW), lds, 0, a); });
+        std::vector<float> r((size_t)N * ld), o((size_t)N * ld);
+        hipMemcpy(r.data(), d_ref, r.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(o.data(), d_out, o.size() * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (int64_t i = 0; i < N; ++i) for (int c = 0; c < F; ++c) bad += memcmp(&r[i * ld + c], &o[i * ld + c], 4) != 0;
+        printf("%-17s avg %.1f us  best %.1f us  mismatching elements %zu  (%s)\n", name, tr.first, tr.second, bad, hipGetErrorString(hipGetLastError()));
+    };
+    run("ring", k_ring<3, 4, false>);
+    {   // one stamped launch of the prefetching variant: wall clock is 100 MHz
+        RingArgs b = a; b.stamps = d_st;
+        hipLaunchKernelGGL((k_ring<3, 4, true>), dim3((unsigned)grid), dim3(64 * RW), lds, 0, b);
+        long long st[64]; hipMemcpy(st, d_st, sizeof st, hipMemcpyDeviceToHost);
+        printf("stamps of workgroup 0 (us since start):");
+        for (int i = 1; i < 64 && st[i]; ++i) printf(" %.2f", (st[i] - st[0]) / 100.0);
+        printf("\n");
+    }
+    run("ring+pre", k_ring<3, 4, true>);
+    run("ring+pre nb2", k_ring<3, 2, true>);
+    return 0;
+}
