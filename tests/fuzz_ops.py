@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Random shapes through the projection, aggregation and level-epilogue operators against float64 torch on the device.
+  python3 tests/fuzz_ops.py [cases] [seed]     (prints the first failing case and exits 1)
+``run(cases, seed)`` is what tests/test_gpu_fuzz.py calls."""
+import os
+import random
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DEV = torch.device("cuda:0")
+
+
+def rel(a, b, scale=None):
+    """max |a - b| over the natural scale of the result: max |b|, or for sums of products the largest sum of |terms| (a sum
+    that cancels to ~0 has no relative accuracy of its own)."""
+    a, b = a.detach().double(), b.detach().double()
+    s = float(b.abs().max()) if scale is None else float(scale)
+    return float((a - b).abs().max()) / max(s, 1e-30)
+
+
+def fuzz_linear(rng, gen):
+    from hgvae_amd import functional as Fn
+    m = rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 63, 100, 257, 1000, 4097, rng.randint(1, 20000)])
+    k1 = rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 28, 56, 60, 105, 128, 138, 256, rng.randint(1, 288)])
+    k2 = rng.choice([0, 0, 1, 5, 6, 28, 105, 138, 256, rng.randint(1, 288)])
+    n = rng.choice([1, 2, 3, 4, 6, 28, 56, 60, 105, 128, 138, 256, rng.randint(1, 288)])
+    bias = rng.random() < 0.7
+    xa = torch.randn(m, k1, device=DEV, generator=gen).requires_grad_(True)
+    wa = (torch.randn(n, k1, device=DEV, generator=gen) * 0.2).requires_grad_(True)
+    xb = torch.randn(m, k2, device=DEV, generator=gen).requires_grad_(True) if k2 else None
+    wb = (torch.randn(n, k2, device=DEV, generator=gen) * 0.2).requires_grad_(True) if k2 else None
+    b = torch.randn(n, device=DEV, generator=gen).requires_grad_(True) if bias else None
+    y = Fn.dual_linear(xa, wa, xb, wb, b)
+    g = torch.randn(m, n, device=DEV, generator=gen)
+    y.backward(g)
+    want = xa.detach().double() @ wa.detach().double().t()
+    if k2:
+        want = want + xb.detach().double() @ wb.detach().double().t()
+    if bias:
+        want = want + b.detach().double()
+    xa64, wa64, g64 = xa.detach().double(), wa.detach().double(), g.double()
+    sy = xa64.abs() @ wa64.abs().t()
+    if k2:
+        sy = sy + xb.detach().double().abs() @ wb.detach().double().abs().t()
+    errs = {"y": rel(y, want, sy.max()), "gxa": rel(xa.grad, g64 @ wa64, (g64.abs() @ wa64.abs()).max()),
+            "gwa": rel(wa.grad, g64.t() @ xa64, (g64.abs().t() @ xa64.abs()).max())}
+    if k2:
+        xb64, wb64 = xb.detach().double(), wb.detach().double()
+        errs["gxb"] = rel(xb.grad, g64 @ wb64, (g64.abs() @ wb64.abs()).max())
+        errs["gwb"] = rel(wb.grad, g64.t() @ xb64, (g64.abs().t() @ xb64.abs()).max())
+    if bias:
+        errs["gb"] = rel(b.grad, g64.sum(0), g64.abs().sum(0).max())
+    return f"linear m={m} k1={k1} k2={k2} n={n} bias={bias}", errs, 1e-6
+
+
+def fuzz_aggregate(rng, gen):
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    n = rng.choice([1, 2, 7, 64, 65, 1000, rng.randint(1, 30000)])
+    e = rng.choice([0, 1, n, 5 * n, rng.randint(0, 12 * n)])
+    f = rng.choice([1, 2, 3, 4, 5, 6, 28, 56, 60, 105, 128, 138, 256, 276, rng.randint(1, 600)])
+    ei = torch.randint(0, n, (2, e), device=DEV, generator=gen)
+    if e and rng.random() < 0.3:                         # leave a range of nodes without in-edges / out-edges
+        ei = ei % max(n // 2, 1)
+    x = torch.randn(n, f, device=DEV, generator=gen).requires_grad_(True)
+    mean = rng.random() < 0.7
+    g = Graph(ei, n)
+    out = Fn.aggregate(x, g, mean=mean)
+    want = torch.zeros(n, f, dtype=torch.float64, device=DEV)
+    if e:
+        want.index_add_(0, ei[1], x.detach().double()[ei[0]])
+    deg = torch.bincount(ei[1], minlength=n).clamp(min=1).double().unsqueeze(1) if mean else 1.0
+    want = want / deg
+    go = torch.randn(n, f, device=DEV, generator=gen)
+    out.backward(go)
+    wg = torch.zeros(n, f, dtype=torch.float64, device=DEV)
+    if e:
+        wg.index_add_(0, ei[0], (go.double() / deg)[ei[1]])
+    return f"aggregate n={n} e={e} f={f} mean={mean}", {"out": rel(out, want), "gx": rel(x.grad, wg) if float(wg.abs().max()) > 0 else float(x.grad.abs().max())}, 2e-6
+
+
+def fuzz_bn(rng, gen):
+    from hgvae_amd import functional as Fn
+    n = rng.choice([16, 17, 255, 1000, rng.randint(16, 40000)])   # a handful of rows: the input gradient cancels to ~0, no relative measure
+    h = rng.choice([1, 2, 3, 4, 6, 28, 60, 105, 128, 138, 256, rng.randint(1, 288)])
+    relu = rng.random() < 0.6
+    bn = torch.nn.BatchNorm1d(h).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(torch.randn(h, device=DEV, generator=gen))
+        bn.bias.copy_(torch.randn(h, device=DEV, generator=gen))
+    y = (torch.randn(n, h, device=DEV, generator=gen) * 2 + 0.5).requires_grad_(True)
+    out = Fn.bn_act(y, bn, relu, 0.0, True)
+    go = torch.randn(n, h, device=DEV, generator=gen)
+    out.backward(go)
+    yd = y.detach().double().requires_grad_(True)
+    a = torch.relu(yd) if relu else yd
+    w64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.batch_norm(a, None, None, w64, b64, True, 0.1, bn.eps)
+    ref.backward(go.double())
+    return f"bn n={n} h={h} relu={relu}", {"out": rel(out, ref), "gy": rel(y.grad, yd.grad), "gw": rel(bn.weight.grad, w64.grad),
+                                         "gb": rel(bn.bias.grad, b64.grad)}, 2e-4
+
+
+def run(cases: int, seed: int, verbose: bool = False):
+    """(failure message or None, worst error per quantity)."""
+    rng = random.Random(seed)
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    worst = {}
+    for i in range(cases):
+        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn])
+        name, errs, tol = fn(rng, gen)
+        for k, v in errs.items():
+            key = fn.__name__ + "." + k
+            worst[key] = max(worst.get(key, 0.0), v)
+            if not v <= tol:
+                return f"case {i} (seed {seed}): {name}: {k} = {v:.3e} (> {tol:g})", worst
+        if verbose and i % 50 == 49:
+            print(f"{i + 1} cases ok", flush=True)
+    return None, worst
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fail, worst = run(cases, seed, verbose=True)
+    if fail:
+        print("FAIL", fail)
+        sys.exit(1)
+    print("worst relative errors:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
+
+
+if __name__ == "__main__":
+    main()
