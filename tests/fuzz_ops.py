@@ -44,6 +44,8 @@ def fuzz_linear(rng, gen):
     sy = xa64.abs() @ wa64.abs().t()
     if k2:
         sy = sy + xb.detach().double().abs() @ wb.detach().double().abs().t()
+    if bias:
+        sy = sy + b.detach().double().abs()
     errs = {"y": rel(y, want, sy.max()), "gxa": rel(xa.grad, g64 @ wa64, (g64.abs() @ wa64.abs()).max()),
             "gwa": rel(wa.grad, g64.t() @ xa64, (g64.abs().t() @ xa64.abs()).max())}
     if k2:
@@ -103,13 +105,60 @@ def fuzz_bn(rng, gen):
                                          "gb": rel(bn.bias.grad, b64.grad)}, 2e-4
 
 
+def fuzz_csr(rng, gen):
+    """Both CSR directions against torch's stable sort of the edge list (integer work: exact)."""
+    from hgvae_amd.graph import Graph
+    n = rng.choice([1, 2, 255, 256, 257, 4096, rng.randint(1, 200000)])
+    e = rng.choice([0, 1, 2, n, rng.randint(0, 8 * n)])
+    ei = torch.randint(0, n, (2, e), device=DEV, generator=gen)
+    if rng.random() < 0.3:
+        ei = ei.t().contiguous().t()                       # [2, E] view of an [E, 2] buffer
+    g = Graph(ei, n)
+    bad = 0
+    for csr, key_row, other_row in ((g.by_dst, 1, 0), (g.by_src, 0, 1)):
+        order = torch.sort(ei[key_row], stable=True).indices
+        rp = torch.zeros(n + 1, dtype=torch.long, device=DEV)
+        rp[1:] = torch.cumsum(torch.bincount(ei[key_row], minlength=n), 0)
+        ok = torch.equal(csr.perm.long(), order) and torch.equal(csr.col.long(), ei[other_row][order]) and \
+            torch.equal(csr.rowptr.long(), rp)
+        bad += 0 if ok else 1
+    return f"csr n={n} e={e}", {"mismatch": float(bad)}, 0.0
+
+
+def fuzz_pool(rng, gen):
+    """Per-graph top-k (ties included) and filter_adj against the CPU restatement (integer results: exact)."""
+    from oracle import pyg_ops as O
+    from hgvae_amd import functional as Fn
+    b = rng.choice([1, 2, 5, 33])
+    sizes = [rng.choice([1, 2, 3, 100, 1023, 1024, 1025, rng.randint(1, 6000)]) for _ in range(b)]
+    n = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(b), torch.tensor(sizes))
+    cpu_gen = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+    score = torch.tanh(torch.randn(n, generator=cpu_gen))
+    if rng.random() < 0.5:
+        score = (score * 4).round() / 4                    # many ties
+    ratio = rng.choice([0.5, 0.3, 1.0, 0.01])
+    ref = O.topk(score, ratio, batch)
+    bad = 0
+    for global_sort in (False, True):
+        perm = Fn.topk_perm(score.to(DEV), ratio, batch.to(DEV), global_sort=global_sort)
+        bad += 0 if torch.equal(perm.cpu(), ref) else 1
+    e = rng.randint(0, 6 * n)
+    ei = torch.randint(0, n, (2, e), generator=cpu_gen)
+    ea = torch.randn(e, 1, generator=cpu_gen)
+    ref_ei, ref_ea = O.filter_adj(ei, ea, ref, n)
+    out_ei, out_ea = Fn.filter_adj(ei.to(DEV), ea.to(DEV), ref.to(DEV), n)
+    bad += 0 if (torch.equal(out_ei.cpu(), ref_ei) and torch.equal(out_ea.cpu(), ref_ea)) else 1
+    return f"pool sizes={sizes} ratio={ratio} e={e}", {"mismatch": float(bad)}, 0.0
+
+
 def run(cases: int, seed: int, verbose: bool = False):
     """(failure message or None, worst error per quantity)."""
     rng = random.Random(seed)
     gen = torch.Generator(device=DEV).manual_seed(seed)
     worst = {}
     for i in range(cases):
-        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn])
+        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn, fuzz_csr, fuzz_pool])
         name, errs, tol = fn(rng, gen)
         for k, v in errs.items():
             key = fn.__name__ + "." + k
