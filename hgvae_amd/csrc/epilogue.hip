@@ -9,8 +9,8 @@
 //
 // The activation is never materialised: the statistics pass and the normalise pass both
 // recompute d from the pre-activation y (3 N*H floats of traffic instead of 5).
-// Column statistics: each workgroup reduces a row range with sums shifted by the range's
-// first row (no catastrophic cancellation), writes (mean_b, M2_b); a second tiny kernel
+// Column statistics: each workgroup reduces a row range with sums shifted by the mean of the
+// range's first rows (no catastrophic cancellation), writes (mean_b, M2_b); a second tiny kernel
 // merges the partials with Chan's formula in fp64.  No atomics -> bitwise reproducible.
 //
 // Thread mapping: a thread owns the 4-column chunks cp and cp + CP of a row (CP = half the chunks, so
@@ -123,17 +123,34 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
     int cc[2];
     chunk_cols(a, cp, cc);
-    if (active && rsub == 0) {
-        float4 yv[2], d[2];
-        yv[0] = ld4<VEC>(a.y, a.ldy, r0, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, r0, cc[1], a.H);
-        apply_d2(a, r0, cp, yv, d);
-        sh[2 * cp] = d[0]; sh[2 * cp + 1] = d[1];
+    // shift of the sums: the column mean over the block's first rows (one per row slot).  A single row as the shift can
+    // sit several standard deviations from the mean, and S2 - S1^2/n then loses that factor squared in fp32 - visible
+    // when a batch has only a few hundred rows in all.
+    {
+        float4 d[2];
+        d[0] = d[1] = make_float4(0, 0, 0, 0);
+        if (active && r0 + rsub < r1) {
+            float4 yv[2];
+            yv[0] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[1], a.H);
+            apply_d2(a, r0 + rsub, cp, yv, d);
+        }
+        sh[2 * t] = d[0]; sh[2 * t + 1] = d[1];
     }
     __syncthreads();
     float4 s[2], S1[2], S2[2];
     s[0] = s[1] = S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
     if (active) {
-        s[0] = sh[2 * cp]; s[1] = sh[2 * cp + 1];
+        const int cnt = (int)min((int64_t)a.RPB, r1 - r0);
+        for (int r = 0; r < cnt; ++r) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 u = sh[2 * (r * a.CP + cp) + h];
+                s[h].x += u.x; s[h].y += u.y; s[h].z += u.z; s[h].w += u.w;
+            }
+        }
+        const float inv = 1.f / (float)cnt;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { s[h].x *= inv; s[h].y *= inv; s[h].z *= inv; s[h].w *= inv; }
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
             float4 yv[2], d[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
