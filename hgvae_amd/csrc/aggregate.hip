@@ -163,9 +163,10 @@ int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
         vec >>= 1;
     a.nchunks = (int)hgv_cdiv(F, vec);
     // lanes per row L (power of two, >= 8 so that a group reads >= 128 contiguous bytes with 16-byte
-    // chunks) and chunks per lane (<= 5): the fewest lane slots L x CPL >= nchunks; ties go to the
-    // narrower group (more rows per wave, fewer index shuffles per row).  35 chunks (width 138) run as
-    // 8 lanes x 5 chunks (40 slots) rather than 16 x 3 (48): measured 3 % faster.
+    // chunks) and chunks per lane (<= 4): the fewest lane slots L x CPL >= nchunks; ties go to the
+    // narrower group (more rows per wave, fewer index shuffles per row).  (8 lanes x 5 chunks for the 35
+    // chunks of width 138 - 40 slots instead of 48 - is 3 % faster for the plain sum in isolation, equal
+    // inside the train step and 5 % slower for the weighted sum: not used.)
     int ls = 0, cpl = 1;
     {
         int64_t best = -1;
@@ -173,7 +174,7 @@ int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
             const int Lc = 1 << l;
             if (Lc < 8 && Lc < a.nchunks) continue;
             int c = (int)hgv_cdiv(a.nchunks, Lc);
-            if (c > 5) continue;
+            if (c > 4) continue;
             if (c < 1) c = 1;
             const int64_t slots = (int64_t)Lc * c;
             if (best < 0 || slots < best) { best = slots; ls = l; cpl = c; }
@@ -196,7 +197,6 @@ int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
         case 1: hipLaunchKernelGGL((k_aggregate<V, W, 1, 4>), g, b, 0, st, a); break;              \
         case 2: hipLaunchKernelGGL((k_aggregate<V, W, 2, 4>), g, b, 0, st, a); break;              \
         case 3: hipLaunchKernelGGL((k_aggregate<V, W, 3, 2>), g, b, 0, st, a); break;              \
-        case 5: hipLaunchKernelGGL((k_aggregate<V, W, 5, 2>), g, b, 0, st, a); break;              \
         default: hipLaunchKernelGGL((k_aggregate<V, W, 4, 2>), g, b, 0, st, a); break;             \
     }
 #define HGV_AGG_LAUNCH(V)                                                                          \

@@ -110,6 +110,8 @@ __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, c
     }
 }
 
+constexpr int EP_PIVOT_ROWS = 8;
+
 // partial layout: [block][2][Hp] = (mean_b, M2_b), Hp = CH*4
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial) {
@@ -123,24 +125,24 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
     int cc[2];
     chunk_cols(a, cp, cc);
-    // shift of the sums: the column mean over the block's first rows (one per row slot).  A single row as the shift can
-    // sit several standard deviations from the mean, and S2 - S1^2/n then loses that factor squared in fp32 - visible
-    // when a batch has only a few hundred rows in all.
+    // shift of the sums: the column mean over the block's first EP_PIVOT_ROWS rows.  A single row as the shift can sit
+    // several standard deviations from the mean, and S2 - S1^2/n then loses that factor squared in fp32 - visible when
+    // a batch has only a few hundred rows in all; any shift within about one standard deviation is as good as the mean.
     {
         float4 d[2];
         d[0] = d[1] = make_float4(0, 0, 0, 0);
-        if (active && r0 + rsub < r1) {
+        if (active && rsub < EP_PIVOT_ROWS && r0 + rsub < r1) {
             float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[1], a.H);
             apply_d2(a, r0 + rsub, cp, yv, d);
         }
-        sh[2 * t] = d[0]; sh[2 * t + 1] = d[1];
+        if (rsub < EP_PIVOT_ROWS) { sh[2 * t] = d[0]; sh[2 * t + 1] = d[1]; }
     }
     __syncthreads();
     float4 s[2], S1[2], S2[2];
     s[0] = s[1] = S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
     if (active) {
-        const int cnt = (int)min((int64_t)a.RPB, r1 - r0);
+        const int cnt = (int)min((int64_t)min(a.RPB, EP_PIVOT_ROWS), r1 - r0);
         for (int r = 0; r < cnt; ++r) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -167,24 +169,34 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
     __syncthreads();
     if (active && rsub == 0) {
+        // the row slots' sums are added in fp64 (up to 256 of them for narrow rows), and so is M2 = S2 - S1^2 / n
+        double D1[2][4], D2[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            D1[h][0] = S1[h].x; D1[h][1] = S1[h].y; D1[h][2] = S1[h].z; D1[h][3] = S1[h].w;
+            D2[h][0] = S2[h].x; D2[h][1] = S2[h].y; D2[h][2] = S2[h].z; D2[h][3] = S2[h].w;
+        }
         for (int r = 1; r < a.RPB; ++r) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
-                S1[h].x += u.x; S1[h].y += u.y; S1[h].z += u.z; S1[h].w += u.w;
-                S2[h].x += w.x; S2[h].y += w.y; S2[h].z += w.z; S2[h].w += w.w;
+                D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
+                D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
             }
         }
-        const float n = (float)(r1 - r0);
+        const double n = (double)(r1 - r0);
         const int Hp = a.CH * 4;
         for (int h = 0; h < nh; ++h) {
-            float4 m, q;
-            m.x = s[h].x + S1[h].x / n; m.y = s[h].y + S1[h].y / n; m.z = s[h].z + S1[h].z / n; m.w = s[h].w + S1[h].w / n;
-            q.x = S2[h].x - S1[h].x * S1[h].x / n; q.y = S2[h].y - S1[h].y * S1[h].y / n;
-            q.z = S2[h].z - S1[h].z * S1[h].z / n; q.w = S2[h].w - S1[h].w * S1[h].w / n;
+            const float sv[4] = {s[h].x, s[h].y, s[h].z, s[h].w};
+            float mv[4], qv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mv[e] = (float)((double)sv[e] + D1[h][e] / n);
+                qv[e] = (float)(D2[h][e] - D1[h][e] * D1[h][e] / n);
+            }
             const int c0 = (cp + h * a.CP) * 4;
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = m;
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = q;
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = make_float4(qv[0], qv[1], qv[2], qv[3]);
         }
     }
 }
@@ -382,19 +394,27 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
     sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
     __syncthreads();
     if (active && rsub == 0) {
+        double D1[2][4], D2[2][4];       // row slots added in fp64 (up to 256 of them for narrow rows)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            D1[h][0] = S1[h].x; D1[h][1] = S1[h].y; D1[h][2] = S1[h].z; D1[h][3] = S1[h].w;
+            D2[h][0] = S2[h].x; D2[h][1] = S2[h].y; D2[h][2] = S2[h].z; D2[h][3] = S2[h].w;
+        }
         for (int r = 1; r < a.RPB; ++r) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
-                S1[h].x += u.x; S1[h].y += u.y; S1[h].z += u.z; S1[h].w += u.w;
-                S2[h].x += w.x; S2[h].y += w.y; S2[h].z += w.z; S2[h].w += w.w;
+                D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
+                D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
             }
         }
         const int Hp = a.CH * 4;
         for (int h = 0; h < nh; ++h) {
             const int c0 = (cp + h * a.CP) * 4;
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = S1[h];
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = S2[h];
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) =
+                make_float4((float)D1[h][0], (float)D1[h][1], (float)D1[h][2], (float)D1[h][3]);
+            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) =
+                make_float4((float)D2[h][0], (float)D2[h][1], (float)D2[h][2], (float)D2[h][3]);
         }
     }
 }

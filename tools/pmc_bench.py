@@ -2,7 +2,7 @@
 """Counter summary of one bench.py workload -> gpurun_out/pmc/pmc_<workload>_b<graphs>.json; bench.py reads the copy
 kept under profiles/.
 
-  python3 tools/pmc_bench.py --workload protein256 [--agg-kernel 'k_aggregate<4, false, 5, 2>' --agg-width 138]
+  python3 tools/pmc_bench.py --workload protein256 [--agg-kernel 'k_aggregate<4, false, 3, 2>' --agg-width 138]
 
 Three rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE), each at two step
 counts; per-step figures are the difference of the two runs divided by the difference in steps, so warm-up, the
@@ -50,7 +50,7 @@ def run_pass(counters, workload, steps, out, extra):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="protein256")
-    ap.add_argument("--agg-kernel", default="k_aggregate<4, false, 5, 2>")
+    ap.add_argument("--agg-kernel", default="k_aggregate<4, false, 3, 2>")
     ap.add_argument("--agg-width", type=int, default=138)
     ap.add_argument("--steps", type=int, nargs=2, default=[3, 9])
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc"))
