@@ -153,14 +153,17 @@ def fuzz_pool(rng, gen):
 
 
 def fuzz_model(rng, gen):
-    """One skip-connection train step (loss and every parameter gradient) on a random batch of random graphs with random
-    widths against the float64 CPU restatement driven by the same noise tape."""
+    """One train step (loss and every parameter gradient) of one of the four model variants on a random batch of random
+    graphs with random widths against the float64 CPU restatement driven by the same noise tape."""
     from oracle import models as OM
     from oracle import pyg_ops as O
+    from hgvae_amd import vae as V
     from hgvae_amd.noise import NoiseTape, use_noise
-    from hgvae_amd.vae import SkipconVAE, train_step_loss
-    from test_gpu_model import _fresh_state, randomize_bn, skipcon_tape
+    from test_gpu_model import _fresh_state, pool_tape, randomize_bn, skipcon_tape
+    kind = rng.choice(["skipcon", "skipcon", "attention", "pool", "custom_pool"])
     f_in, h = rng.choice([3, 6, 60, 105]), rng.choice([4, 30, 64, 138, 200])
+    if kind in ("pool", "custom_pool"):
+        h = min(h, 138)                                    # their second level is 2h wide; projections stop at 288 columns
     z, ns = rng.choice([1, 2, 28]), rng.choice([1, 3, 10])
     sizes = [rng.choice([1, 2, 40, 138, rng.randint(1, 700)]) for _ in range(rng.choice([1, 3, 8]))]
     n = max(sum(sizes), 64)
@@ -172,46 +175,73 @@ def fuzz_model(rng, gen):
     lo = torch.cumsum(torch.tensor([0] + sizes[:-1]), 0)[batch[src]]                     # keep every edge inside its graph
     dst = lo + (torch.rand(e, generator=cpu_gen) * torch.tensor(sizes)[batch[src]]).long()
     ei = torch.stack([src, dst])
+    if kind == "attention":
+        ei = ei[:, src != dst]                             # the attention layer replaces self loops by its own: keep the count simple
+    e = ei.size(1)
     x = torch.randn(n, f_in, generator=cpu_gen)
     torch.manual_seed(rng.randint(0, 1 << 30))
-    ref32 = OM.SkipconVAE(f_in, h, z, ns)
+    if kind == "skipcon":
+        make, dev_cls = (lambda: OM.SkipconVAE(f_in, h, z, ns)), V.SkipconVAE
+        tape = None
+        ref_loss = lambda m, xx, t: OM.skipcon_loss(m, xx, ei, batch, 1.0, t)[0]       # noqa: E731
+        dev_loss = lambda m, xx, ee, bb: V.train_step_loss(m, xx, ee, bb, 1.0)           # noqa: E731
+        mk_tape = lambda: skipcon_tape(n, h, z, ns, 0.5, cpu_gen)                        # noqa: E731
+    elif kind == "attention":
+        make, dev_cls = (lambda: OM.SkipconAttentionVAE(f_in, h, z, ns)), V.SkipconAttentionVAE
+        ref_loss = lambda m, xx, t: OM.skipcon_loss(m, xx, ei, batch, 1.0, t)[0]       # noqa: E731
+        dev_loss = lambda m, xx, ee, bb: V.train_step_loss(m, xx, ee, bb, 1.0)           # noqa: E731
+        mk_tape = lambda: skipcon_tape(n, h, z, ns, 0.49, cpu_gen, gat_edges=e + n)      # noqa: E731
+    elif kind == "pool":
+        make, dev_cls = (lambda: OM.PoolVAE(f_in, h, z, ns)), V.PoolVAE
+        ref_loss = lambda m, xx, t: OM.pool_loss(m, xx, ei, batch, 1.0, t)[0]          # noqa: E731
+        dev_loss = lambda m, xx, ee, bb: V.train_step_loss(m, xx, ee, bb, 1.0)           # noqa: E731
+        mk_tape = lambda: pool_tape(n, h, z, ns, cpu_gen)                                # noqa: E731
+    else:
+        make, dev_cls = (lambda: OM.CustomPoolVAE(f_in, h, z, ns, beta=0.5)), (lambda *a: V.CustomPoolVAE(*a, beta=0.5))
+        ref_loss = lambda m, xx, t: OM.custom_pool_loss(m, xx, ei, batch, t)[0]        # noqa: E731
+        dev_loss = lambda m, xx, ee, bb: V.custom_pool_step_loss(m, xx, ee, bb)          # noqa: E731
+        mk_tape = lambda: pool_tape(n, h, z, ns, cpu_gen, second_encode=False, second_decode=True)   # noqa: E731
+    ref32 = make()
     randomize_bn(ref32, cpu_gen)
     state = _fresh_state(ref32)
-    tape = skipcon_tape(n, h, z, ns, 0.5, cpu_gen)
-    ref = OM.SkipconVAE(f_in, h, z, ns).double()
+    tape = mk_tape()
+    ref = make().double()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in state.items()})
     ref.train()
     tape64 = [t.double() if t.is_floating_point() else t for t in tape]
-    loss_ref = OM.skipcon_loss(ref, x.double(), ei, batch, 1.0, O.NoiseTape(tape64))[0]
+    loss_ref = ref_loss(ref, x.double(), O.NoiseTape(tape64))
     loss_ref.backward()
-    mod = SkipconVAE(f_in, h, z, ns)
+    mod = dev_cls(f_in, h, z, ns)
     mod.load_state_dict(state)
     mod = mod.to(DEV).train()
     with use_noise(NoiseTape(tape)):
-        loss = train_step_loss(mod, x.to(DEV), ei.to(DEV), batch.to(DEV), 1.0)
+        loss = dev_loss(mod, x.to(DEV), ei.to(DEV), batch.to(DEV))
     loss.backward()
     # the same step by the fp32 CPU restatement: how far plain fp32 arithmetic lands from float64 on this case
     # (narrow layers on few nodes are ill-conditioned through the batch statistics); the device path may be 4x that
     ref32.load_state_dict(state)
     ref32.train()
-    loss32 = OM.skipcon_loss(ref32, x, ei, batch, 1.0, O.NoiseTape(tape))[0]
+    loss32 = ref_loss(ref32, x, O.NoiseTape(tape))
     loss32.backward()
     rp, rp32 = dict(ref.named_parameters()), dict(ref32.named_parameters())
-    floor = 1e-6 * max(abs(float(loss_ref)), 1.0)
+    floor = 1e-6 * max(abs(float(loss_ref.detach())), 1.0)
     dev_err = cpu_err = 0.0
     for name, prm in mod.named_parameters():
+        if rp[name].grad is None:                          # parameters outside the loss (the discarded pooling branch)
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
         r = rp[name].grad.double()
         scale = max(float(r.abs().max()), floor)
         dev_err = max(dev_err, float((prm.grad.double().cpu() - r).abs().max()) / scale)
         cpu_err = max(cpu_err, float((rp32[name].grad.double() - r).abs().max()) / scale)
-    lscale = max(abs(float(loss_ref)), 1e-30)
-    dev_loss, cpu_loss = abs(float(loss) - float(loss_ref)) / lscale, abs(float(loss32) - float(loss_ref)) / lscale
+    lscale = max(abs(float(loss_ref.detach())), 1e-30)
+    dev_l, cpu_l = abs(float(loss.detach()) - float(loss_ref.detach())) / lscale, abs(float(loss32.detach()) - float(loss_ref.detach())) / lscale
     # bars: loss 1e-5, gradients 2e-4 (reported on the gradient scale, hence the factor 20), each widened to 4x the fp32 CPU error
-    errs = {"loss": 20 * dev_loss / max(1.0, 4 * cpu_loss / 1e-5), "grad": dev_err / max(1.0, 4 * cpu_err / 2e-4)}
+    errs = {"loss": 20 * dev_l / max(1.0, 4 * cpu_l / 1e-5), "grad": dev_err / max(1.0, 4 * cpu_err / 2e-4)}
     if os.environ.get("FUZZ_MODEL_DETAIL"):
-        print(f"  model detail: loss dev {float(loss):.9g} cpu32 {float(loss32):.9g} f64 {float(loss_ref):.12g}; rel dev {dev_loss:.2e} cpu32 {cpu_loss:.2e}; "
+        print(f"  model detail: {kind} loss f64 {float(loss_ref.detach()):.9g}; rel dev {dev_l:.2e} cpu32 {cpu_l:.2e}; "
               f"grad dev {dev_err:.2e} cpu32 {cpu_err:.2e}; h={h} n={n} e={e}", flush=True)
-    return f"model f_in={f_in} h={h} z={z} ns={ns} sizes={sizes} e={e} (fp32 CPU grad err {cpu_err:.1e})", errs, 2e-4
+    return f"model {kind} f_in={f_in} h={h} z={z} ns={ns} sizes={sizes} e={e} (fp32 CPU grad err {cpu_err:.1e})", errs, 2e-4
 
 
 def run(cases: int, seed: int, verbose: bool = False):
