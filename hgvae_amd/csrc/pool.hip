@@ -46,8 +46,42 @@ __global__ void k_topk_select(const int32_t* __restrict__ ids_sorted, const int6
 // One workgroup per graph whose node count fits the LDS table: the graph's (descending-score key, local node index)
 // pairs are sorted as 64-bit words by a bitonic network in LDS (total order: ties in the score fall back to the
 // ascending node index, the order of a stable sort) and the first k[g] entries go straight to perm.
-constexpr int SEG_CAP = 16384;             // 128 KB of 64-bit words
+// The network's steps are taken up to four at a time: a thread loads the 16 words whose indices differ in the four
+// stride bits of the group, runs the 32 compare-exchanges in registers and writes the words back, so the 105 steps of
+// a 16384-word table cost 32 passes over LDS (the sort is bound by LDS bandwidth: one CU moves the whole table per pass).
+// Word i lives at slot i + i / 16, which spreads the 16-word strides of the low groups over the banks.
+constexpr int SEG_CAP = 16384;             // words per table
 constexpr int SEG_THREADS = 1024;
+__host__ __device__ inline int seg_slot(int i) { return i + (i >> 4); }
+inline size_t seg_lds_bytes(int m) { return (size_t)(seg_slot(m - 1) + 1) * 8; }
+
+// steps with stride bits b, b-1, ..., b-NST+1 of the merge of width `size`
+template <int NST>
+__device__ __forceinline__ void topk_group(unsigned long long* tab, int m, int size, int b) {
+    constexpr int E = 1 << NST;
+    const int lowbit = b - NST + 1;
+    for (int t = threadIdx.x; t < (m >> NST); t += SEG_THREADS) {
+        const int low = t & ((1 << lowbit) - 1), high = t >> lowbit;
+        const int base = (high << (b + 1)) | low;
+        const bool up = (base & size) == 0;
+        unsigned long long r[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) r[e] = tab[seg_slot(base | (e << lowbit))];
+#pragma unroll
+        for (int j = NST - 1; j >= 0; --j) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if ((e >> j) & 1) continue;
+                const unsigned long long x = r[e], y = r[e | (1 << j)];
+                const bool sw = (x > y) == up;
+                r[e] = sw ? y : x;
+                r[e | (1 << j)] = sw ? x : y;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) tab[seg_slot(base | (e << lowbit))] = r[e];
+    }
+}
 
 __global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __restrict__ score, const int64_t* __restrict__ ptr,
                                                               const int64_t* __restrict__ k, const int64_t* __restrict__ kptr,
@@ -66,8 +100,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __res
         for (int r = threadIdx.x; r < kg; r += SEG_THREADS) perm[base + r] = lo + (r < n ? r : n - 1);
         return;
     }
-    int m = 1;
-    while (m < n) m <<= 1;                 // table size: next power of two, padded with keys that sort last
+    int m = 1, logm = 0;
+    while (m < n) { m <<= 1; ++logm; }     // table size: next power of two, padded with keys that sort last
     for (int i = threadIdx.x; i < m; i += SEG_THREADS) {
         unsigned long long w = ~0ull;
         if (i < n) {
@@ -76,23 +110,23 @@ __global__ __launch_bounds__(SEG_THREADS) void k_topk_segment(const float* __res
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);              // ascending in the score
             w = ((unsigned long long)(~u) << 32) | (unsigned)i;           // descending score, then ascending index
         }
-        tab[i] = w;
+        tab[seg_slot(i)] = w;
     }
     __syncthreads();
-    for (int size = 2; size <= m; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < (m >> 1); t += SEG_THREADS) {
-                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));    // lower element of pair t
-                const int j = i | stride;
-                const bool up = (i & size) == 0;
-                const unsigned long long a = tab[i], b = tab[j];
-                if ((a > b) == up) { tab[i] = b; tab[j] = a; }
-            }
+    for (int ls = 1; ls <= logm; ++ls) {                                   // merge width 2^ls: stride bits ls-1 ... 0
+        const int size = 1 << ls;
+        for (int b = ls - 1; b >= 0;) {
+            const int nst = b + 1 < 4 ? b + 1 : 4;
+            if (nst == 4) topk_group<4>(tab, m, size, b);
+            else if (nst == 3) topk_group<3>(tab, m, size, b);
+            else if (nst == 2) topk_group<2>(tab, m, size, b);
+            else topk_group<1>(tab, m, size, b);
+            b -= nst;
             __syncthreads();
         }
     }
     const int64_t base = kptr[g];
-    for (int r = threadIdx.x; r < kg; r += SEG_THREADS) perm[base + r] = lo + (int64_t)(tab[r] & 0xffffffffull);
+    for (int r = threadIdx.x; r < kg; r += SEG_THREADS) perm[base + r] = lo + (int64_t)(tab[seg_slot(r)] & 0xffffffffull);
 }
 
 __global__ void k_fill_i32(int32_t* __restrict__ p, int64_t n, int32_t v) {
@@ -232,11 +266,11 @@ extern "C" int hgv_topk_perm(const float* score, const int64_t* batch, const int
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!raised[dev]) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_topk_segment),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, SEG_CAP * 8);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds_bytes(SEG_CAP));
             HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "topk_perm: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
             raised[dev] = true;
         }
-        hipLaunchKernelGGL(k_topk_segment, dim3((unsigned)B), dim3(SEG_THREADS), (size_t)m * 8, stream, score, ptr, k, kptr, perm, m);
+        hipLaunchKernelGGL(k_topk_segment, dim3((unsigned)B), dim3(SEG_THREADS), seg_lds_bytes(m), stream, score, ptr, k, kptr, perm, m);
         HGV_CHECK_LAUNCH("topk_perm(segmented)");
         return HGV_OK;
     }
