@@ -19,7 +19,7 @@
 //   d logit_k = (alpha'_k dad_k - alpha_k S_i) lk_k,   d a_dst[i] = sum_k d logit_k,   d a_src[j] = sum over
 //   the out-edges of j,   d xw[j] = sum over the out-edges (j -> i) of alpha'_k g_i.
 // k_gat_bwd_rows walks the by-target CSR (gathers xw rows against the row's g_i held in registers) and
-// writes S_i and d a_dst[i] = sum alpha' dad lk - S_i sum alpha lk.  k_gat_bwd_cols walks the by-source
+// writes S_i and d a_dst[i], both as sums of differences from a value near S_i (see there).  k_gat_bwd_cols walks the by-source
 // CSR: it holds xw[j] in registers, gathers g_i once per edge for both the dot product and the weighted
 // sum, and recomputes alpha / the keep decision of every edge from (a_src[j], a_dst[i], max_i, normaliser_i,
 // edge id), so no per-edge array and no permutation between the two CSR orders is needed.  No atomics.
@@ -40,7 +40,7 @@ struct GatArgs {
     const float* bias;
     float* out; int64_t ldo;            // forward: out; backward over sources: d xw
     float* row_max; float* row_den;     // per target row: max logit, sum exp + 1e-16
-    float* S;                           // per target row: sum_k alpha'_k dad_k
+    float* S;                           // per target row i: S_i = sum_k alpha'_k dad_k as r_i (S[i]) + V_i (S[N + i])
     float* da; int64_t ld_da;           // rows kernel: d a_dst; cols kernel: d a_src (element stride ld_da)
     const float* da_other;              // cols kernel: d a_dst of the rows kernel (same stride), for the logit projection term
     const float* att_src; const float* att_dst;   // cols kernel, nullable: a_src = <xw, att_src>, a_dst = <xw, att_dst>; then
@@ -183,15 +183,20 @@ __global__ __launch_bounds__(128) void k_gat_bwd_rows(const GatArgs a) {
     const int start = a.rowptr[row], end = a.rowptr[row + 1];
     const float ad = a.a_dst[row * a.ldd_], m = a.row_max[row], s = a.row_den[row];
     const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
-    float S = 0.f, T1 = 0.f, T2 = 0.f;
+    // With t_k = m_k dad_k - r (m_k the keep multiplier, r a value near the row's S taken from the first L edges):
+    //   S = r + sum_k alpha_k t_k,   d a_dst[i] = sum_k alpha_k lk_k (m_k dad_k - S) = U - V T2   (sum_k alpha_k = 1),
+    //   U = sum alpha lk t, V = sum alpha t, T2 = sum alpha lk.
+    // All sums run over differences from r: when the softmax is sharp (or all dad_k alike) they are small, while the plain
+    // sum alpha' dad lk - S sum alpha lk subtracts two numbers of the size of dad itself.
+    float U = 0.f, V = 0.f, T2 = 0.f, r = 0.f;
     for (int base = start; base < end; base += L) {
         const int k = base + lr;
-        int my_col = 0; float al = 0.f, ap = 0.f, lk = 0.f;
+        int my_col = 0; float al = 0.f, mk = 0.f, lk = 0.f;
         if (k < end) {
             my_col = a.col[k];
             const float raw = a.a_src[(int64_t)my_col * a.lds_] + ad;
             al = expf(leaky(raw, a.slope) - m) / s;
-            ap = al * edge_keep(a, (uint32_t)a.perm[k], off);
+            mk = edge_keep(a, (uint32_t)a.perm[k], off);
             lk = raw > 0.f ? 1.f : a.slope;
         }
         const int cnt = min(L, end - base);
@@ -210,12 +215,17 @@ __global__ __launch_bounds__(128) void k_gat_bwd_rows(const GatArgs a) {
             if (lr == j) my_dad = d0;
             if (lr == j + 1) my_dad = d1;
         }
-        S += ap * my_dad;
-        T1 += ap * my_dad * lk;
+        if (base == start) {
+            const float num = grp_sum(al * mk * my_dad, L), den = grp_sum(al * mk, L);
+            r = den > 0.f ? num / den : 0.f;
+        }
+        const float t = k < end ? mk * my_dad - r : 0.f;
+        U += al * lk * t;
+        V += al * t;
         T2 += al * lk;
     }
-    S = grp_sum(S, L); T1 = grp_sum(T1, L); T2 = grp_sum(T2, L);
-    if (lr == 0) { a.S[row] = S; a.da[row * a.ld_da] = T1 - S * T2; }
+    U = grp_sum(U, L); V = grp_sum(V, L); T2 = grp_sum(T2, L);
+    if (lr == 0) { a.S[row] = r; a.S[a.N + row] = V; a.da[row * a.ld_da] = U - V * T2; }
 }
 
 // by-source rows (rowptr / col / perm of the transposed CSR): d xw[j] and d a_src[j]
@@ -233,14 +243,15 @@ __global__ __launch_bounds__(128) void k_gat_bwd_cols(const GatArgs a) {
     float dsum = 0.f;
     for (int base = start; base < end; base += L) {
         const int t = base + lr;
-        int my_col = 0; float al = 0.f, ap = 0.f, lk = 0.f, Si = 0.f;
+        int my_col = 0; float al = 0.f, ap = 0.f, mk = 0.f, lk = 0.f, ri = 0.f, Vi = 0.f;
         if (t < end) {
             my_col = a.col[t];                                    // target i of this out-edge
             const float raw = as + a.a_dst[(int64_t)my_col * a.ldd_];
             al = expf(leaky(raw, a.slope) - a.row_max[my_col]) / a.row_den[my_col];
-            ap = al * edge_keep(a, (uint32_t)a.perm[t], off);
+            mk = edge_keep(a, (uint32_t)a.perm[t], off);
+            ap = al * mk;
             lk = raw > 0.f ? 1.f : a.slope;
-            Si = a.S[my_col];
+            ri = a.S[my_col]; Vi = a.S[a.N + my_col];
         }
         const int cnt = min(L, end - base);
         float my_dad = 0.f;
@@ -268,7 +279,7 @@ __global__ __launch_bounds__(128) void k_gat_bwd_cols(const GatArgs a) {
             if (lr == j) my_dad = d0;
             if (lr == j + 1) my_dad = d1;
         }
-        dsum += (ap * my_dad - al * Si) * lk;
+        dsum += al * ((mk * my_dad - ri) - Vi) * lk;      // S_i = r_i + V_i kept in two parts: both differences are small where the softmax is sharp
     }
     dsum = grp_sum(dsum, L);
     const float dd = a.att_src ? a.da_other[row * a.ld_da] : 0.f;
@@ -359,7 +370,7 @@ extern "C" int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int3
 
 // Backward of hgv_gat_fwd for the output gradient g [N, C]: gxw [N, C] (d xw), da_src [N], da_dst [N].  The by-target
 // CSR (rowptr / col / perm) and the by-source CSR (rowptr_t / col_t / perm_t) of the same edge list, the forward's
-// noise arguments and its row_max / row_den are needed; S [N] is scratch.  da_src / da_dst are written with element stride
+// noise arguments and its row_max / row_den are needed; S [2N] is scratch.  da_src / da_dst are written with element stride
 // ld_da (two columns of one [N, ld] matrix).  att_src / att_dst (nullable, [ceil(C/4)*4], 16-byte aligned): when the logits
 // were formed as a_src = <xw, att_src>, a_dst = <xw, att_dst>, the gradient that reaches xw through them
 // (da_src[j] att_src + da_dst[j] att_dst) is added to gxw in the same pass.

@@ -817,7 +817,7 @@ class _GatAggregate(torch.autograd.Function):
         g = as_padded(g)
         csr, csr_t = lg.by_dst, lg.by_src
         dev = xw.device
-        scratch = torch.empty(n, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * n, dtype=torch.float32, device=dev)
         da = new_padded(n, 2, dev)                                     # d a_src | d a_dst
         att_p = new_padded(2, c, dev)                                  # rows padded to 16 bytes for the kernel's chunk loads
         att_p.copy_(att.detach())

@@ -183,7 +183,7 @@ int hgv_gat_fwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, 
                 float* out, int64_t ldo, float* row_max, float* row_den, hgv_stream_t stream);
 /* Backward (autograd of the above, loss.backward() gvae/gvae_skipcon_attention.py:181) for the output gradient g [N, C]:
  * gxw [N, C] = d xw, da_src [N], da_dst [N].  Takes both CSRs of the same edge list (rowptr_t / col_t / perm_t = by
- * source), the forward's noise arguments and row_max / row_den; S [N] is scratch.  Two kernels (one per CSR direction),
+ * source), the forward's noise arguments and row_max / row_den; S [2N] is scratch.  Two kernels (one per CSR direction),
  * each recomputing the attention weights of its edges; same layout contract as hgv_gat_fwd for g / xw / gxw.  da_src /
  * da_dst are written with element stride ld_da.  att_src / att_dst (nullable, padded to ceil(C/4)*4 floats, 16-byte
  * aligned): if the logits are a_src = <xw, att_src>, a_dst = <xw, att_dst> (GATConv's att parameters), the part of d xw

@@ -152,6 +152,122 @@ def fuzz_pool(rng, gen):
     return f"pool sizes={sizes} ratio={ratio} e={e}", {"mismatch": float(bad)}, 0.0
 
 
+def fuzz_gat(rng, gen):
+    """Single-head graph attention (no attention dropout) against a masked dense softmax in float64: duplicate edges, self loops
+    in the input (replaced by the layer's own), isolated nodes."""
+    from oracle import pyg_ops as O
+    from hgvae_amd.nn import GATConv
+    n = rng.choice([1, 2, 17, 200, rng.randint(1, 900)])
+    e = rng.choice([0, n, rng.randint(0, 10 * n)])
+    f_in, c = rng.choice([1, 3, 30, 138]), rng.choice([1, 4, 30, 138, 256])
+    cpu_gen = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+    ei = torch.randint(0, n, (2, e), generator=cpu_gen)
+    x = torch.randn(n, f_in, generator=cpu_gen)
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    conv = GATConv(f_in, c)
+    with torch.no_grad():
+        conv.bias.copy_(torch.randn(c, generator=cpu_gen))
+        conv.att_src.mul_(rng.choice([1.0, 8.0]))          # sharper softmax
+    ref = {k: v.detach().double().requires_grad_(True) for k, v in conv.named_parameters()}
+    xr = x.double().requires_grad_(True)
+    want = O.dense_gat(xr, ei, ref["lin_src.weight"], ref["att_src"], ref["att_dst"], ref["bias"])
+    go = torch.randn(n, c, generator=cpu_gen)
+    want.backward(go.double())
+    # the per-edge algorithm (what PyG runs) in fp32 on the CPU: a sharp softmax makes the attention gradients differences of
+    # terms that cancel - per edge, so that parallel edges do not merge as they do in the dense form - and fp32 arithmetic
+    # then sits far (relatively) from float64: the bar follows it (x4)
+    cpu = O.GATConv(f_in, c)
+    cpu.load_state_dict({k: v.detach().clone() for k, v in conv.state_dict().items()})
+    ref32 = dict(cpu.named_parameters())
+    x32 = x.clone().requires_grad_(True)
+    cpu(x32, ei).backward(go)
+    conv = conv.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = conv(xd, ei.to(DEV))
+    out.backward(go.to(DEV))
+    tol = 2e-5
+    errs = {"out": rel(out.cpu(), want)}
+    # a shift of all logits of a row leaves its softmax unchanged, so the gradient of att_dst is a sum that cancels to (almost)
+    # zero wherever the leaky slope is the same along the row: both attention vectors are measured on their common scale
+    att_scale = max(float(ref["att_src"].grad.abs().max()), float(ref["att_dst"].grad.abs().max()), 1e-6)
+    pairs = [("gx", xd.grad, xr.grad, x32.grad, max(float(xr.grad.abs().max()), 1e-6))]
+    for k, v in conv.named_parameters():
+        scale = att_scale if k.startswith("att_") else max(float(ref[k].grad.abs().max()), 1e-6)
+        pairs.append(("g_" + k.split(".")[0], v.grad, ref[k].grad, ref32[k].grad, scale))
+    raw = {}
+    for name, got, r64, r32, scale in pairs:
+        raw[name] = (rel(got.cpu(), r64, scale), rel(r32, r64, scale))
+        errs[name] = raw[name][0] / max(1.0, 4 * raw[name][1] / tol)
+    if os.environ.get("FUZZ_GAT_DETAIL"):
+        print(f"  gat detail n={n} e={e} f_in={f_in} c={c}: att scale {att_scale:.3e}, |go| {float(go.abs().max()):.2e}, out scale "
+              f"{float(want.abs().max()):.2e}, dev/cpu32 errs " + " ".join(f"{k}={v[0]:.1e}/{v[1]:.1e}" for k, v in raw.items()), flush=True)
+    return f"gat n={n} e={e} f_in={f_in} c={c}", errs, tol
+
+
+def fuzz_losses(rng, gen):
+    """Reparameterisation, KL term and mean squared error (values and gradients) against float64, with log-std values
+    far from zero."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import NoiseTape, use_noise
+    n = rng.choice([1, 2, 63, 1000, rng.randint(1, 30000)])
+    z, ns = rng.choice([1, 2, 28, 56]), rng.choice([1, 3, 10])
+    spread = rng.choice([0.1, 1.0, 3.0])
+    ml = torch.randn(n, 2 * z, device=DEV, generator=gen)
+    ml[:, z:] *= spread
+    ml.requires_grad_(True)
+    eps = torch.randn(ns, n, z, device=DEV, generator=gen)
+    with use_noise(NoiseTape([eps.cpu()])):
+        zz = Fn.reparameterize(ml, z, ns)
+    kl = Fn.kl_divergence(ml, z)
+    gz = torch.randn(n, z, device=DEV, generator=gen)
+    (zz * gz).sum().backward(retain_graph=True)
+    g_rep = ml.grad.clone(); ml.grad = None
+    kl.backward()
+    g_kl = ml.grad.clone()
+    m64 = ml.detach().double().requires_grad_(True)
+    mean, ls = m64[:, :z], m64[:, z:]
+    z64 = (mean.unsqueeze(0) + ls.exp().unsqueeze(0) * eps.double()).mean(0)
+    kl64 = (-0.5 * torch.sum(1 + 2 * ls - mean.pow(2) - ls.exp().pow(2), dim=-1)).mean()
+    (z64 * gz.double()).sum().backward(retain_graph=True)
+    r_rep = m64.grad.clone(); m64.grad = None
+    kl64.backward()
+    r_kl = m64.grad.clone()
+    a = torch.randn(n, z, device=DEV, generator=gen).requires_grad_(True)
+    b = torch.randn(n, z, device=DEV, generator=gen)
+    mse = Fn.mse_loss(a, b)
+    mse.backward()
+    a64 = a.detach().double().requires_grad_(True)
+    mse64 = torch.nn.functional.mse_loss(a64, b.double())
+    mse64.backward()
+    errs = {"z": rel(zz, z64), "g_reparam": rel(g_rep, r_rep),
+            "kl": abs(float(kl.detach()) - float(kl64.detach())) / max(abs(float(kl64.detach())), 1e-30), "g_kl": rel(g_kl, r_kl),
+            "mse": abs(float(mse.detach()) - float(mse64.detach())) / max(float(mse64.detach()), 1e-30), "g_mse": rel(a.grad, a64.grad)}
+    return f"losses n={n} z={z} ns={ns} spread={spread}", errs, 2e-6
+
+
+def fuzz_adam(rng, gen):
+    """A few optimiser steps on random parameter shapes against torch.optim.Adam + clip_grad_norm_ (same fp32 arithmetic)."""
+    from hgvae_amd.optim import FlatAdam
+    shapes = [tuple(rng.randint(1, 40) for _ in range(rng.choice([1, 2]))) for _ in range(rng.randint(1, 6))]
+    lr, wd = rng.choice([1e-3, 1e-2, 0.3]), rng.choice([0.0, 0.0, 1e-2])
+    eps, betas = rng.choice([1e-8, 1e-5]), rng.choice([(0.9, 0.999), (0.5, 0.9)])
+    clip = rng.choice([None, None, 0.5, 10.0])
+    ps = [torch.nn.Parameter(torch.randn(sh, device=DEV, generator=gen)) for sh in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FlatAdam(ps, lr=lr, betas=betas, eps=eps, weight_decay=wd, max_grad_norm=clip)
+    ref = torch.optim.Adam(qs, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    for _ in range(rng.randint(1, 5)):
+        for p, q in zip(ps, qs):
+            g = torch.randn(p.shape, device=DEV, generator=gen) * rng.choice([1e-3, 1.0, 30.0])
+            p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
+            q.grad = g.clone()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(qs, clip)
+        opt.step(); ref.step()
+    err = max(rel(p, q) for p, q in zip(ps, qs))
+    return f"adam shapes={shapes} lr={lr} wd={wd} eps={eps} betas={betas} clip={clip}", {"param": err}, 1e-5
+
+
 def fuzz_model(rng, gen):
     """One train step (loss and every parameter gradient) of one of the four model variants on a random batch of random
     graphs with random widths against the float64 CPU restatement driven by the same noise tape."""
@@ -250,7 +366,7 @@ def run(cases: int, seed: int, verbose: bool = False):
     gen = torch.Generator(device=DEV).manual_seed(seed)
     worst = {}
     for i in range(cases):
-        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn, fuzz_csr, fuzz_pool, fuzz_model])
+        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn, fuzz_csr, fuzz_pool, fuzz_model, fuzz_gat, fuzz_losses, fuzz_adam])
         name, errs, tol = fn(rng, gen)
         for k, v in errs.items():
             key = fn.__name__ + "." + k
