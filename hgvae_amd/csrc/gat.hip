@@ -304,13 +304,13 @@ __global__ __launch_bounds__(128) void k_gat_bwd_cols(const GatArgs a) {
 
 bool vec4_ok(const float* p, int64_t ld, int nchunks) { return p && hgv_aligned(p, 16) && ld % 4 == 0 && ld >= (int64_t)nchunks * 4; }
 
-// lanes per row (>= 8 unless the row has fewer chunks) x chunks per lane (<= 4): the fewest lane slots
+// lanes per row (>= 8: the lanes of a row also hold one edge each, and the backward pass takes its pivot from the first
+// L edges of a row) x chunks per lane (<= 4): the fewest lane slots
 void pick_lanes(int nchunks, int* ls, int* cpl) {
     int64_t best = -1;
     *ls = 6; *cpl = 4;
-    for (int l = 0; l <= 6; ++l) {
+    for (int l = 3; l <= 6; ++l) {
         const int Lc = 1 << l;
-        if (Lc < 8 && Lc < nchunks) continue;
         int c = (int)hgv_cdiv(nchunks, Lc);
         if (c > 4) continue;
         if (c < 1) c = 1;

@@ -204,6 +204,45 @@ def fuzz_gat(rng, gen):
     return f"gat n={n} e={e} f_in={f_in} c={c}", errs, tol
 
 
+def fuzz_convs(rng, gen):
+    """SAGEConv / GraphConv / GCNConv modules (outputs, input and parameter gradients) against the CPU restatement in float64
+    on random multigraphs with self loops and isolated nodes."""
+    from oracle import pyg_ops as O
+    from hgvae_amd import nn as HN
+    kind = rng.choice(["SAGEConv", "GraphConv", "GCNConv"])
+    n = rng.choice([1, 2, 33, 500, rng.randint(1, 3000)])
+    e = rng.choice([0, n, rng.randint(0, 10 * n)])
+    f_in, f_out = rng.choice([1, 3, 6, 60, 105, 138, 276]), rng.choice([1, 2, 28, 56, 138, 276])
+    cpu_gen = torch.Generator().manual_seed(rng.randint(0, 1 << 30))
+    ei = torch.randint(0, n, (2, e), generator=cpu_gen)
+    if e and rng.random() < 0.3:
+        ei = ei % max(n // 3, 1)                           # most nodes isolated
+    x = torch.randn(n, f_in, generator=cpu_gen)
+    torch.manual_seed(rng.randint(0, 1 << 30))
+    ref = getattr(O, kind)(f_in, f_out).double()
+    mod = getattr(HN, kind)(f_in, f_out)
+    mod.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    mod = mod.to(DEV)
+    xr = x.double().requires_grad_(True)
+    want = ref(xr, ei)
+    go = torch.randn(n, f_out, generator=cpu_gen)
+    want.backward(go.double())
+    xd = x.to(DEV).requires_grad_(True)
+    out = mod(xd, ei.to(DEV))
+    out.backward(go.to(DEV))
+    # scale of a sum of products: the same network on absolute values
+    with torch.no_grad():
+        aref = getattr(O, kind)(f_in, f_out).double()
+        aref.load_state_dict({k: v.abs() for k, v in ref.state_dict().items()})
+        scale_out = float(aref(x.double().abs(), ei).abs().max())
+    errs = {"out": rel(out.cpu(), want, max(scale_out, 1e-30)),
+            "gx": rel(xd.grad.cpu(), xr.grad, max(float(xr.grad.abs().max()), 1e-6))}
+    rp = dict(ref.named_parameters())
+    for k, v in mod.named_parameters():
+        errs["g_" + k] = rel(v.grad.cpu(), rp[k].grad, max(float(rp[k].grad.abs().max()), 1e-6))
+    return f"{kind} n={n} e={e} f_in={f_in} f_out={f_out}", errs, 5e-6
+
+
 def fuzz_losses(rng, gen):
     """Reparameterisation, KL term and mean squared error (values and gradients) against float64, with log-std values
     far from zero."""
@@ -366,7 +405,7 @@ def run(cases: int, seed: int, verbose: bool = False):
     gen = torch.Generator(device=DEV).manual_seed(seed)
     worst = {}
     for i in range(cases):
-        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn, fuzz_csr, fuzz_pool, fuzz_model, fuzz_gat, fuzz_losses, fuzz_adam])
+        fn = rng.choice([fuzz_linear, fuzz_linear, fuzz_aggregate, fuzz_bn, fuzz_csr, fuzz_pool, fuzz_model, fuzz_gat, fuzz_losses, fuzz_adam, fuzz_convs, fuzz_convs])
         name, errs, tol = fn(rng, gen)
         for k, v in errs.items():
             key = fn.__name__ + "." + k
