@@ -662,6 +662,40 @@ class _BnAct(torch.autograd.Function):
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 12
 
 
+class _BnActEval(torch.autograd.Function):
+    """Evaluation mode: relu? -> identity -> batch norm with the running statistics, an elementwise affine map.  Its
+    backward pass is the rare case (fine-tuning with frozen statistics, input gradients of a trained model) and is
+    written with torch's elementwise device operators."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, eps):
+        y = rowmajor(y)
+        out = new_padded(y.size(0), y.size(1), y.device, zero_pad=not is_vec4(y))
+        _lib.call("hgv_bn_act_eval", y.data_ptr(), ld_of(y), y.size(0), y.size(1), int(relu), _lib.ptr(gamma),
+                  _lib.ptr(beta), float(eps), running_mean.data_ptr(), running_var.data_ptr(),
+                  out.data_ptr(), ld_of(out), _lib.stream())
+        ctx.relu, ctx.eps, ctx.has_gamma, ctx.has_beta = bool(relu), float(eps), gamma is not None, beta is not None
+        ctx.save_for_backward(y, gamma, running_mean, running_var)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y, gamma, rm, rv = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        rstd = torch.rsqrt(rv + ctx.eps)
+        a = torch.relu(y) if ctx.relu else y
+        gy = dgamma = dbeta = None
+        if need[0]:
+            gy = g * (rstd * gamma if ctx.has_gamma else rstd)
+            if ctx.relu:
+                gy = gy * (y > 0)
+        if ctx.has_gamma and need[1]:
+            dgamma = (g * ((a - rm) * rstd)).sum(0)
+        if ctx.has_beta and need[2]:
+            dbeta = g.sum(0)
+        return gy, dgamma, dbeta, None, None, None, None
+
+
 def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
     """relu? -> Dropout(p) -> BatchNorm1d, fused.  ``bn`` supplies affine parameters and running buffers.  With ``fork``
     the result is returned as a pair of handles for its two consumers (see :class:`_BnAct`)."""
@@ -670,12 +704,7 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
         out = bn_act(y, bn, relu, p, training)
         return out, out
     if not training:
-        y = rowmajor(y)
-        out = new_padded(y.size(0), y.size(1), y.device, zero_pad=not is_vec4(y))
-        _lib.call("hgv_bn_act_eval", y.data_ptr(), ld_of(y), y.size(0), y.size(1), int(relu), _lib.ptr(bn.weight),
-                  _lib.ptr(bn.bias), float(bn.eps), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                  out.data_ptr(), ld_of(out), _lib.stream())
-        return out
+        return _BnActEval.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, bn.eps)
     mask, seed, offset, ctr = None, 0, 0, None
     if p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)

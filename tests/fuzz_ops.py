@@ -101,8 +101,22 @@ def fuzz_bn(rng, gen):
     w64, b64 = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
     ref = torch.nn.functional.batch_norm(a, None, None, w64, b64, True, 0.1, bn.eps)
     ref.backward(go.double())
-    return f"bn n={n} h={h} relu={relu}", {"out": rel(out, ref), "gy": rel(y.grad, yd.grad), "gw": rel(bn.weight.grad, w64.grad),
-                                         "gb": rel(bn.bias.grad, b64.grad)}, 2e-4
+    errs = {"out": rel(out, ref), "gy": rel(y.grad, yd.grad), "gw": rel(bn.weight.grad, w64.grad), "gb": rel(bn.bias.grad, b64.grad)}
+    # running statistics after the step, then the evaluation-mode path that uses them (forward and input gradient)
+    m64 = a.detach().mean(0)
+    errs["running_mean"] = rel(bn.running_mean, 0.1 * m64, max(float(m64.abs().max()), 1e-3))
+    errs["running_var"] = rel(bn.running_var, 0.9 + 0.1 * a.detach().var(0, unbiased=True))
+    bn.eval()
+    y2 = y.detach().clone().requires_grad_(True)
+    out2 = Fn.bn_act(y2, bn, relu, 0.3, False)
+    out2.backward(go)
+    y2d = y.detach().double().requires_grad_(True)
+    a2 = torch.relu(y2d) if relu else y2d
+    ref2 = torch.nn.functional.batch_norm(a2, bn.running_mean.double(), bn.running_var.double(), w64.detach(), b64.detach(), False, 0.1, bn.eps)
+    ref2.backward(go.double())
+    errs["eval_out"] = rel(out2, ref2)
+    errs["eval_gy"] = rel(y2.grad, y2d.grad)
+    return f"bn n={n} h={h} relu={relu}", errs, 2e-5
 
 
 def fuzz_csr(rng, gen):
@@ -285,7 +299,8 @@ def fuzz_losses(rng, gen):
 
 
 def fuzz_adam(rng, gen):
-    """A few optimiser steps on random parameter shapes against torch.optim.Adam + clip_grad_norm_ (same fp32 arithmetic)."""
+    """A few optimiser steps on random parameter shapes against torch.optim.Adam + clip_grad_norm_ in float64; torch's own
+    fp32 run of the same steps sets how far fp32 arithmetic may land (clipped, tiny gradients against a large eps are touchy)."""
     from hgvae_amd.optim import FlatAdam
     shapes = [tuple(rng.randint(1, 40) for _ in range(rng.choice([1, 2]))) for _ in range(rng.randint(1, 6))]
     lr, wd = rng.choice([1e-3, 1e-2, 0.3]), rng.choice([0.0, 0.0, 1e-2])
@@ -293,18 +308,24 @@ def fuzz_adam(rng, gen):
     clip = rng.choice([None, None, 0.5, 10.0])
     ps = [torch.nn.Parameter(torch.randn(sh, device=DEV, generator=gen)) for sh in shapes]
     qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    rs = [torch.nn.Parameter(p.detach().double().clone()) for p in ps]
     opt = FlatAdam(ps, lr=lr, betas=betas, eps=eps, weight_decay=wd, max_grad_norm=clip)
-    ref = torch.optim.Adam(qs, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    t32 = torch.optim.Adam(qs, lr=lr, betas=betas, eps=eps, weight_decay=wd)
+    t64 = torch.optim.Adam(rs, lr=lr, betas=betas, eps=eps, weight_decay=wd)
     for _ in range(rng.randint(1, 5)):
-        for p, q in zip(ps, qs):
+        for p, q, r in zip(ps, qs, rs):
             g = torch.randn(p.shape, device=DEV, generator=gen) * rng.choice([1e-3, 1.0, 30.0])
             p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
-            q.grad = g.clone()
+            q.grad, r.grad = g.clone(), g.double()
         if clip is not None:
             torch.nn.utils.clip_grad_norm_(qs, clip)
-        opt.step(); ref.step()
-    err = max(rel(p, q) for p, q in zip(ps, qs))
-    return f"adam shapes={shapes} lr={lr} wd={wd} eps={eps} betas={betas} clip={clip}", {"param": err}, 1e-5
+            torch.nn.utils.clip_grad_norm_(rs, clip)
+        opt.step(); t32.step(); t64.step()
+    dev_err = max(rel(p, r) for p, r in zip(ps, rs))
+    cpu_err = max(rel(q, r) for q, r in zip(qs, rs))
+    tol = 1e-6
+    return (f"adam shapes={shapes} lr={lr} wd={wd} eps={eps} betas={betas} clip={clip} (torch fp32 {cpu_err:.1e})",
+            {"param": dev_err / max(1.0, 4 * cpu_err / tol)}, tol)
 
 
 def fuzz_model(rng, gen):

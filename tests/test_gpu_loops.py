@@ -329,3 +329,48 @@ def test_pool_variants_replay_as_a_captured_step(variant):
     assert sum(losses[-5:]) < sum(losses[:5])
     # the reference train step of vae_with_pool encodes twice per step, the custom-pool one once
     assert int(model.encoder1[2].num_batches_tracked) == (60 if variant == "pool" else 30)
+
+
+def test_evaluation_mode_stays_differentiable():
+    """model.eval() only freezes dropout and the batch statistics; gradients still flow (fine-tuning with frozen statistics,
+    input gradients of a trained model) exactly as through torch's modules."""
+    import torch
+    from oracle import models as OM
+    from oracle import pyg_ops as O
+    from hgvae_amd.noise import NoiseTape, use_noise
+    from hgvae_amd.vae import SkipconVAE
+    from graphs import path_batch
+    gen = torch.Generator().manual_seed(3)
+    ei, n, batch = path_batch([40, 77])
+    x = torch.randn(n, 60, generator=gen)
+    torch.manual_seed(3)
+    ref = OM.SkipconVAE(60, 138, 28, 3).double()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen).double() * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen).double() + 0.5)
+    ref.eval()
+    eps = torch.randn(3, n, 28, generator=gen)
+    xr = x.double().requires_grad_(True)
+    rec_ref = ref(xr, ei, batch, O.NoiseTape([eps.double()]))[0]
+    rec_ref.square().mean().backward()
+    dev = torch.device("cuda:0")
+    mod = SkipconVAE(60, 138, 28, 3)
+    mod.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+    mod = mod.to(dev).eval()
+    before = {k: v.clone() for k, v in mod.named_buffers()}
+    xd = x.to(dev).requires_grad_(True)
+    with use_noise(NoiseTape([eps])):
+        rec = mod(xd, ei.to(dev), batch.to(dev))[0]
+    rec.square().mean().backward()
+    assert xd.grad is not None and float(xd.grad.abs().max()) > 0
+    scale = float(xr.grad.abs().max())
+    assert float((xd.grad.double().cpu() - xr.grad).abs().max()) <= 1e-4 * scale
+    rp = dict(ref.named_parameters())
+    for name, p in mod.named_parameters():
+        assert p.grad is not None, name
+        r = rp[name].grad
+        assert float((p.grad.double().cpu() - r).abs().max()) <= 1e-4 * max(float(r.abs().max()), 1e-6), name
+    for name, b in mod.named_buffers():                      # evaluation leaves the statistics alone
+        assert torch.equal(b, before[name]), name
