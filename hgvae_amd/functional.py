@@ -792,7 +792,8 @@ class _MSE(torch.autograd.Function):
         gr = new_padded(r.size(0), r.size(1), r.device)
         _lib.call("hgv_mse_bwd", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1), g.data_ptr(),
                   gr.data_ptr(), ld_of(gr), _lib.stream())
-        return gr, None
+        # the target's gradient is the negative of the reconstruction's (only asked for when the input itself needs one)
+        return (gr if ctx.needs_input_grad[0] else None), (-gr if ctx.needs_input_grad[1] else None)
 
 
 def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:

@@ -250,10 +250,10 @@ def fuzz_convs(rng, gen):
         aref.load_state_dict({k: v.abs() for k, v in ref.state_dict().items()})
         scale_out = float(aref(x.double().abs(), ei).abs().max())
     errs = {"out": rel(out.cpu(), want, max(scale_out, 1e-30)),
-            "gx": rel(xd.grad.cpu(), xr.grad, max(float(xr.grad.abs().max()), 1e-6))}
+            "gx": rel(xd.grad.cpu(), xr.grad, max(float(xr.grad.abs().max()), 0.1 * float(go.abs().max())))}
     rp = dict(ref.named_parameters())
     for k, v in mod.named_parameters():
-        errs["g_" + k] = rel(v.grad.cpu(), rp[k].grad, max(float(rp[k].grad.abs().max()), 1e-6))
+        errs["g_" + k] = rel(v.grad.cpu(), rp[k].grad, max(float(rp[k].grad.abs().max()), 0.1 * float(go.abs().max())))
     return f"{kind} n={n} e={e} f_in={f_in} f_out={f_out}", errs, 5e-6
 
 
@@ -384,32 +384,50 @@ def fuzz_model(rng, gen):
     ref = make().double()
     ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in state.items()})
     ref.train()
-    tape64 = [t.double() if t.is_floating_point() else t for t in tape]
-    loss_ref = ref_loss(ref, x.double(), O.NoiseTape(tape64))
-    loss_ref.backward()
     mod = dev_cls(f_in, h, z, ns)
     mod.load_state_dict(state)
     mod = mod.to(DEV).train()
+    ref32.load_state_dict(state)
+    ref32.train()
+    # sometimes a random part of the parameters is frozen and / or the input asks for its gradient
+    frozen = set()
+    if rng.random() < 0.35:
+        frozen = {name for name, _ in mod.named_parameters() if rng.random() < 0.35}
+        for m in (ref, ref32, mod):
+            for name, prm in m.named_parameters():
+                if name in frozen:
+                    prm.requires_grad_(False)
+    want_gx = rng.random() < 0.35
+    x64, x32, xd = x.double(), x.clone(), x.to(DEV)
+    if want_gx:
+        x64.requires_grad_(True); x32.requires_grad_(True); xd.requires_grad_(True)
+    tape64 = [t.double() if t.is_floating_point() else t for t in tape]
+    loss_ref = ref_loss(ref, x64, O.NoiseTape(tape64))
+    loss_ref.backward()
     with use_noise(NoiseTape(tape)):
-        loss = dev_loss(mod, x.to(DEV), ei.to(DEV), batch.to(DEV))
+        loss = dev_loss(mod, xd, ei.to(DEV), batch.to(DEV))
     loss.backward()
     # the same step by the fp32 CPU restatement: how far plain fp32 arithmetic lands from float64 on this case
     # (narrow layers on few nodes are ill-conditioned through the batch statistics); the device path may be 4x that
-    ref32.load_state_dict(state)
-    ref32.train()
-    loss32 = ref_loss(ref32, x, O.NoiseTape(tape))
+    loss32 = ref_loss(ref32, x32, O.NoiseTape(tape))
     loss32.backward()
     rp, rp32 = dict(ref.named_parameters()), dict(ref32.named_parameters())
     floor = 1e-6 * max(abs(float(loss_ref.detach())), 1.0)
     dev_err = cpu_err = 0.0
     for name, prm in mod.named_parameters():
-        if rp[name].grad is None:                          # parameters outside the loss (the discarded pooling branch)
+        if rp[name].grad is None:                          # frozen, or outside the loss (the discarded pooling branch)
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
             continue
+        assert prm.grad is not None, name
         r = rp[name].grad.double()
         scale = max(float(r.abs().max()), floor)
         dev_err = max(dev_err, float((prm.grad.double().cpu() - r).abs().max()) / scale)
         cpu_err = max(cpu_err, float((rp32[name].grad.double() - r).abs().max()) / scale)
+    if want_gx:
+        assert xd.grad is not None
+        scale = max(float(x64.grad.abs().max()), floor)
+        dev_err = max(dev_err, float((xd.grad.double().cpu() - x64.grad).abs().max()) / scale)
+        cpu_err = max(cpu_err, float((x32.grad.double() - x64.grad).abs().max()) / scale)
     lscale = max(abs(float(loss_ref.detach())), 1e-30)
     dev_l, cpu_l = abs(float(loss.detach()) - float(loss_ref.detach())) / lscale, abs(float(loss32.detach()) - float(loss_ref.detach())) / lscale
     # bars: loss 1e-5, gradients 2e-4 (reported on the gradient scale, hence the factor 20), each widened to 4x the fp32 CPU error
@@ -417,7 +435,8 @@ def fuzz_model(rng, gen):
     if os.environ.get("FUZZ_MODEL_DETAIL"):
         print(f"  model detail: {kind} loss f64 {float(loss_ref.detach()):.9g}; rel dev {dev_l:.2e} cpu32 {cpu_l:.2e}; "
               f"grad dev {dev_err:.2e} cpu32 {cpu_err:.2e}; h={h} n={n} e={e}", flush=True)
-    return f"model {kind} f_in={f_in} h={h} z={z} ns={ns} sizes={sizes} e={e} (fp32 CPU grad err {cpu_err:.1e})", errs, 2e-4
+    return (f"model {kind} f_in={f_in} h={h} z={z} ns={ns} sizes={sizes} e={e} frozen={sorted(frozen)} input_grad={want_gx} "
+            f"(fp32 CPU grad err {cpu_err:.1e})"), errs, 2e-4
 
 
 def run(cases: int, seed: int, verbose: bool = False):
