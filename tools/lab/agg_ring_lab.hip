@@ -18,7 +18,7 @@ namespace {
 struct RingArgs {
     const int32_t* rowptr; const int32_t* col; const float* x; int64_t ldx; int64_t n_rows; int nchunks; int lshift;
     float* out; int64_t ldo;
-    int halo, cap_mask; int64_t rows_per_wg; int mode;
+    int halo, cap, slot4; int64_t rows_per_wg; int mode;      // cap: ring rows; slot4: float4 per ring row (256-byte multiple)
     long long* stamps;      // nullable: wall-clock stamps of workgroup 0 (start, after the first fill, per block: after the sums, after the barrier)
 };
 constexpr int RW = 16;      // waves per workgroup
@@ -31,7 +31,7 @@ __device__ __forceinline__ void batch(float4 (&acc)[CPL], const RingArgs& a, con
     for (int u = 0; u < NB; ++u) {
         const int c = __shfl(my_col, j + u, L);
         if ((a.mode & 1) || (unsigned)(c - win_lo) < win_rows) {
-            const float4* r = ring + (size_t)(c & a.cap_mask) * a.nchunks;
+            const float4* r = ring + (size_t)(c % a.cap) * a.slot4;
 #pragma unroll
             for (int q = 0; q < CPL; ++q) v[u][q] = r[coff[q] >> 2];
         } else {
@@ -60,9 +60,9 @@ __global__ __launch_bounds__(64 * RW) void k_ring(const RingArgs a) {
     int ns = 0;
     const bool stamp = a.stamps && blockIdx.x == 0 && t == 64 * RW - 1;
     if (stamp) a.stamps[ns++] = wall_clock64();
-    const int ring_f4 = (a.cap_mask + 1) * nch;
     const float4* x4 = reinterpret_cast<const float4*>(a.x);          // flat layout: ldx == 4 nch
-    auto dst_of = [&](int64_t lo, int e) __attribute__((always_inline)) { return (int)(((lo & a.cap_mask) * nch + e) % ring_f4); };
+    // element e (row-major over nch float4 per row) of the rows starting at lo -> ring position
+    auto dst_of = [&](int64_t lo, int e) __attribute__((always_inline)) { const int r = e / nch, c = e - r * nch; return (int)((lo + r) % a.cap) * a.slot4 + c; };
     {
         const int64_t lo = max(wb - a.halo, (int64_t)0), hi = min(wb + R + a.halo, a.n_rows);
         const int total = (int)(hi - lo) * nch;
@@ -84,13 +84,21 @@ __global__ __launch_bounds__(64 * RW) void k_ring(const RingArgs a) {
     }
     __syncthreads();
     if (stamp) a.stamps[ns++] = wall_clock64();
-    for (int64_t cur = wb; cur < we; cur += R) {
-        const int64_t nlo = min(cur + R + a.halo, a.n_rows), nhi = cur + R < we ? min(cur + 2 * R + a.halo, a.n_rows) : nlo;
-        const int ntotal = (a.mode & 2) ? 0 : (int)(nhi - nlo) * nch;
-        float4 pf[CPL];
+    // rows of block b + 1 that are not in the ring while block b is reduced: [cur + R + halo, cur + 2R + halo).  They are loaded
+    // into registers one block EARLIER (during block b - 1) and written to the ring after block b, so that the memory latency is
+    // over before the first wait of block b (every wait on a far row also waits for all older loads)
+    auto pf_range = [&](int64_t cur, int64_t& lo, int& total) __attribute__((always_inline)) {
+        lo = min(cur + R + a.halo, a.n_rows);
+        const int64_t hi = cur + R < we ? min(cur + 2 * R + a.halo, a.n_rows) : lo;
+        total = (a.mode & 2) ? 0 : (int)(hi - lo) * nch;
+    };
+    float4 pf[CPL];
+    int64_t nlo; int ntotal;
+    pf_range(wb, nlo, ntotal);
 #pragma unroll
-        for (int u = 0; u < CPL; ++u)
-            if (t + u * 64 * RW < ntotal) pf[u] = x4[nlo * nch + t + u * 64 * RW];
+    for (int u = 0; u < CPL; ++u)
+        if (t + u * 64 * RW < ntotal) pf[u] = x4[nlo * nch + t + u * 64 * RW];
+    for (int64_t cur = wb; cur < we; cur += R) {
         const int64_t row = cur + wrow;
         int start = 0, end = 0, first_col = 0;
         if (PRE) {
@@ -136,6 +144,10 @@ __global__ __launch_bounds__(64 * RW) void k_ring(const RingArgs a) {
 #pragma unroll
         for (int u = 0; u < CPL; ++u)
             if (t + u * 64 * RW < ntotal) ring[dst_of(nlo, t + u * 64 * RW)] = pf[u];
+        pf_range(cur + R, nlo, ntotal);                 // loads for the block after next start now
+#pragma unroll
+        for (int u = 0; u < CPL; ++u)
+            if (t + u * 64 * RW < ntotal) pf[u] = x4[nlo * nch + t + u * 64 * RW];
         __syncthreads();
         if (stamp) a.stamps[ns++] = wall_clock64();
     }
@@ -202,13 +214,16 @@ int main(int argc, char** argv) {
     // lanes per row / chunks per lane as the library picks them
     int ls = 6, cpl = 4; { int64_t best = -1; for (int l = 0; l <= 6; ++l) { const int Lc = 1 << l; if (Lc < 8 && Lc < nch) continue; int c = (nch + Lc - 1) / Lc; if (c > 4) continue; if (best < 0 || (int64_t)Lc * c < best) { best = (int64_t)Lc * c; ls = l; cpl = c; } } }
     const int R = (64 >> ls) * RW;
-    int cap = 1; while ((size_t)(2 * cap) * nch * 16 <= 144 * 1024) cap *= 2;
+    const int slot4 = (nch + 15) / 16 * 16;                       // 256-byte multiples: conflict-free ds_read_b128 lane groups
+    int cap = (int)((size_t)(144 * 1024) / ((size_t)slot4 * 16));
+    if (getenv("RING_TIGHT")) { /* unpadded slots, power-of-two capacity: the first version */ }
     const int halo = (cap - 2 * R) / 2;
+    cap = 2 * R + 2 * halo;
     int64_t grid = std::min<int64_t>(256, (N + 4 * R - 1) / (4 * R));
-    RingArgs a{d_rp, d_col, d_x, ld, N, nch, ls, d_out, ld, halo, cap - 1, ((N + grid - 1) / grid + R - 1) / R * R, mode, nullptr};
+    RingArgs a{d_rp, d_col, d_x, ld, N, nch, ls, d_out, ld, halo, cap, slot4, ((N + grid - 1) / grid + R - 1) / R * R, mode, nullptr};
     long long* d_st; hipMalloc(&d_st, 64 * 8); hipMemset(d_st, 0, 64 * 8);
     grid = (N + a.rows_per_wg - 1) / a.rows_per_wg;
-    const size_t lds = (size_t)cap * nch * 16;
+    const size_t lds = (size_t)cap * slot4 * 16;
     printf("N=%lld E=%lld F=%d  lanes/row %d chunks/lane %d  R=%d halo=%d cap=%d  grid=%lld rows/wg=%lld lds=%zu\n", (long long)N,
            (long long)E, F, 1 << ls, cpl, R, halo, cap, (long long)grid, (long long)a.rows_per_wg, lds);
     {
