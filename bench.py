@@ -61,6 +61,15 @@ def agg_gather_bytes(n, f, e):
     return 4 * f * e + 4 * f * n + 4 * e + 4 * (n + 1)
 
 
+def gather_lines_per_row(f, line=128):
+    """Average number of 128-byte cache lines one gathered row touches: rows of 4 f bytes sit at a stride of 4 ceil(f/4) * 4
+    bytes, so their starting offsets inside a line cycle through the multiples of gcd(stride, line)."""
+    import math
+    stride, data = 4 * ((f + 3) // 4 * 4), 4 * f
+    period = line // math.gcd(stride, line)
+    return sum(((k * stride) % line + data - 1) // line + 1 for k in range(period)) / period
+
+
 def agg_compulsory_bytes(n, f, e, ld=None):
     """Every distinct byte of an aggregation launch once: the feature table read, the output written, col, rowptr."""
     ld = ld or (f + 3) // 4 * 4
@@ -316,9 +325,13 @@ def main():
                     "gather_bytes_per_launch": agg_gather_bytes(n_r, f_r, e_r),
                     "gathered_GBps": round(gathered, 1),
                     "cache_gather_frac": round(gathered / L2_GATHER_GBS, 4),
+                    "gather_lines_GBps": round(e_r * gather_lines_per_row(f_r) * 128 / (us * 1e-6) / 1e9, 1),
+                    "cache_gather_lines_frac": round(e_r * gather_lines_per_row(f_r) * 128 / (us * 1e-6) / 1e9 / L2_GATHER_GBS, 4),
                     "note": "gathered_GBps = one neighbour row per message (4FE + 4FN + 4E + 4(N+1)) / time; the re-reads "
                             "are served by L2 / Infinity Cache, so it is priced against the L2 row-gather rate "
-                            f"({L2_GATHER_GBS:.0f} GB/s), not against HBM",
+                            f"({L2_GATHER_GBS:.0f} GB/s), not against HBM; gather_lines_GBps counts the 128-byte lines the "
+                            "gathered rows touch (a row of 4F bytes at a 16-byte aligned stride straddles lines), which is "
+                            "what the cache moves",
                     "all_unweighted": {"launches_per_step": len(agg) // probe_steps,
                                        "avg_launch_us": round(sum(ms for (_, ms) in agg) / len(agg) * 1e3, 2),
                                        "gathered_GBps": round(rate(agg, agg_gather_bytes), 1),
