@@ -13,7 +13,7 @@ BatchNorm statistics stay rank-local (statistics over the nodes of the local sha
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -129,3 +129,54 @@ def shard_range(num_items: int, rank: int, world: int) -> range:
     base, rem = divmod(num_items, world)
     lo = rank * base + min(rank, rem)
     return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def balanced_ranges(costs: Sequence[int], world: int) -> list:
+    """Contiguous split of graphs with unequal sizes: ``world`` ranges (some possibly empty) over ``costs`` whose
+    largest total is as small as a contiguous split allows.  ``costs[i]`` is the work of graph i - its edge count
+    for a message-passing step.  Every rank calls this with the same list and takes ``[rank]``, so the partition
+    needs no communication; graphs keep their order, which keeps a rank's nodes contiguous in the collated batch.
+    """
+    costs = [int(c) for c in costs]
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    if any(c < 0 for c in costs):
+        raise ValueError("costs must be non-negative")
+
+    def cut(limit):
+        """Greedy ranges with totals <= limit, or None when more than ``world`` are needed."""
+        out, lo, acc = [], 0, 0
+        for i, c in enumerate(costs):
+            if acc + c > limit and i > lo:
+                out.append(range(lo, i))
+                lo, acc = i, 0
+            acc += c
+        out.append(range(lo, len(costs)))
+        return out if len(out) <= world else None
+
+    lo, hi = max(costs, default=0), sum(costs)
+    while lo < hi:                       # smallest feasible bound on a rank's total
+        mid = (lo + hi) // 2
+        if cut(mid) is None:
+            lo = mid + 1
+        else:
+            hi = mid
+    parts = cut(lo)
+    # the greedy cut may need fewer ranges than there are ranks: split the heaviest splittable range at its best
+    # point until every rank has work (a split never raises the largest total)
+    total = lambda r: sum(costs[i] for i in r)
+    while len(parts) < world:
+        wide = [k for k in range(len(parts)) if len(parts[k]) > 1]
+        if not wide:
+            break
+        k = max(wide, key=lambda k: total(parts[k]))
+        r, best, acc, whole = parts[k], None, 0, total(parts[k])
+        for m in range(r.start + 1, r.stop):
+            acc += costs[m - 1]
+            worst = max(acc, whole - acc)
+            if best is None or worst < best[0]:
+                best = (worst, m)
+        parts[k:k + 1] = [range(r.start, best[1]), range(best[1], r.stop)]
+    n = len(costs)
+    parts += [range(n, n)] * (world - len(parts))
+    return parts

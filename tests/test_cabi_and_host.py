@@ -126,3 +126,35 @@ def test_shard_range_balanced_and_contiguous():
         parts = [list(shard_range(n, r, w)) for r in range(w)]
         assert sum(parts, []) == list(range(n))
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_balanced_ranges_minimise_the_heaviest_rank():
+    """Graphs of unequal size (454 ... 15 200 nodes in the bundled set) are split by edge count: contiguous,
+    complete, every rank busy when there are enough graphs, and no contiguous split has a lighter heaviest rank."""
+    import itertools
+    import random
+    from hgvae_amd.distributed import balanced_ranges
+
+    def best_possible(costs, w):
+        n, best = len(costs), None
+        for cuts in itertools.combinations_with_replacement(range(n + 1), w - 1):
+            b = [0, *cuts, n]
+            m = max(sum(costs[b[i]:b[i + 1]]) for i in range(w))
+            best = m if best is None else min(best, m)
+        return best
+
+    sizes = [453, 2626, 4696, 11212, 11454, 11939, 13238, 15199]          # edges of the eight bundled shapes
+    assert balanced_ranges(sizes, 4) == [range(0, 4), range(4, 6), range(6, 7), range(7, 8)]
+    assert balanced_ranges(sizes, 1) == [range(0, 8)]
+    assert balanced_ranges([], 3) == [range(0, 0)] * 3
+    rng = random.Random(3)
+    for _ in range(200):
+        n, w = rng.randint(0, 8), rng.randint(1, 5)
+        costs = [rng.choice([0, 1, 7, 453, 15199, rng.randint(1, 99)]) for _ in range(n)]
+        parts = balanced_ranges(costs, w)
+        assert len(parts) == w and [i for r in parts for i in r] == list(range(n))
+        assert max((sum(costs[i] for i in r) for r in parts), default=0) == best_possible(costs, w)
+        if n >= w:
+            assert all(len(r) for r in parts)
+    with pytest.raises(ValueError):
+        balanced_ranges([1, -1], 2)
