@@ -21,6 +21,7 @@
 // splits them in registers (VALU work, which overlaps with the matrix cores) and reads the weight
 // pieces of each n tile from LDS.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -660,6 +661,11 @@ constexpr int T16_BUF = 3 * T16_PIECE;
 constexpr int T16_THREADS = 768;
 constexpr int T16_SET_FLOATS = 81 * 256;
 
+// Progress counters of paced weight-gradient launches, one per workgroup (64 bytes apart): 32-row steps finished.
+// Hints only, like pace_ctr above.
+constexpr int PACE_TN_AHEAD = 1;
+__device__ int pace_tn[PACE_WGS * 16];
+
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -673,6 +679,7 @@ struct Tn16Args {
     int sets;                  // row slices per group pair
     float* partial;            // [ngrp][kgrp][set][81][4][64]
     float* bias_partial;       // [ngrp][set][9][4][64], written by the workgroups of k group 0 (null: no bias)
+    int paced;                 // two k groups, one n group: the two workgroups of a row slice share an XCD and walk G in step
 };
 
 __device__ __forceinline__ int t16_slot(int r) { return (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1); }
@@ -687,10 +694,12 @@ __device__ __forceinline__ bf16x8 t16_read(const unsigned char* lds, int addr) {
 }
 
 template <int KT>
-__device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds, const int wn, const int k0t, const bool bias) {
+__device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds, const int wn, const int k0t, const bool bias, const bool lead) {
     const int t = threadIdx.x, lane = t & 63;
     const int per = a.ngrps * a.kgrps;
-    const int grp = blockIdx.x % per, set = blockIdx.x / per;
+    // paced: blocks b and b + 8 (same XCD under the round-robin dispatch) are the two k groups of one row slice
+    const int grp = a.paced ? (int)(blockIdx.x >> 3) & 1 : (int)(blockIdx.x % per);
+    const int set = a.paced ? (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7) : (int)(blockIdx.x / per);
     const int ngrp = grp / a.kgrps, kgrp = grp - ngrp * a.kgrps;
     const int second = kgrp >= a.kg0;
     const int n_off = 144 * ngrp, k_off = 144 * (second ? kgrp - a.kg0 : kgrp);
@@ -758,9 +767,19 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
         if (s_lo + 1 < s_hi) load_step(s_lo + 1);
     }
     __syncthreads();
+    // Paced launches: the two workgroups of a row slice read the same rows of G.  Wave 0 publishes the steps its workgroup
+    // has finished and holds the workgroup back at the step barrier while the twin is more than PACE_TN_AHEAD steps
+    // behind, so that the later of the two reads of a G line finds it in the XCD's L2.  The twin's counter is loaded at
+    // the top of a step and looked at after the step's MFMAs; a twin that does not catch up within PACE_SPINS polls
+    // switches the pacing off for the rest of the launch.
+    int* pace_mine = pace_tn + blockIdx.x * 16;
+    const int* pace_twin = pace_tn + (blockIdx.x ^ 8) * 16;
+    bool pace = a.paced != 0 && lead;
     for (int64_t s = s_lo; s < s_hi; ++s) {
         const int b = (int)((s - s_lo) & 1);
         const unsigned char* base = lds + b * T16_BUF;
+        int pace_seen = 0;
+        if (pace) pace_seen = __hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bf16x8 g[3][3], x[KT][3];      // [tile][piece]
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
@@ -785,8 +804,21 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
 #pragma unroll
                 for (int pc = 2; pc >= 0; --pc) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[i][pc], ones, accb[i], 0, 0, 0);
         }
+        if (pace) {
+            const int done = (int)(s - s_lo) + 1;
+            if (lane == 0) __hip_atomic_store(pace_mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(pace_seen) < done - PACE_TN_AHEAD) {
+                for (int spin = 0;; ++spin) {
+                    const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen >= done - PACE_TN_AHEAD) break;
+                    if (spin >= PACE_SPINS) { pace = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
         __syncthreads();
     }
+    if (a.paced != 0 && lead && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // D layout: lane (j = lane & 15, q = lane >> 4), register r: n = 16 tn + 4 q + r, k = 16 tk + j
     float* out = a.partial + ((int64_t)grp * a.sets + set) * T16_SET_FLOATS;
 #pragma unroll
@@ -808,8 +840,8 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tn16(const Tn16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wk = w / 3, wn = w - 3 * wk;
-    if (wk == 0) tn16_body<3>(a, lds_raw, wn, 0, false);
-    else tn16_body<2>(a, lds_raw, wn, 1 + 2 * wk, wk == 1);
+    if (wk == 0) tn16_body<3>(a, lds_raw, wn, 0, false, w == 0);
+    else tn16_body<2>(a, lds_raw, wn, 1 + 2 * wk, wk == 1, false);
 }
 
 struct Tr16Args {
@@ -876,6 +908,15 @@ __global__ __launch_bounds__(256) void k_reduce_tn16(const Tr16Args r) {
 }
 
 struct Tn16Plan { int ngrps, kg0, kgrps, sets; int64_t steps; bool ok; };
+
+// G bytes from which the weight-gradient launch is paced (HGVAE_TN_PACE_MIN_MB: lab override)
+int64_t tn_pace_min_bytes() {
+    static const int64_t v = [] {
+        const char* e = getenv("HGVAE_TN_PACE_MIN_MB");
+        return e ? (int64_t)atoll(e) << 20 : PACE_MIN_BYTES;
+    }();
+    return v;
+}
 
 // Shapes worth the staging: rows for at least a few steps per workgroup and tiles that are mostly live.
 Tn16Plan tn16_plan(int64_t M, int N, int K1, int K2) {
@@ -994,6 +1035,10 @@ extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1
     a.G = G; a.ldg = ldg; a.N = N;
     a.A[0] = A1; a.lda[0] = lda1; a.K[0] = K1; a.A[1] = A2 ? A2 : A1; a.lda[1] = A2 ? lda2 : lda1; a.K[1] = K2;
     a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.M = M; a.steps = p.steps; a.sets = p.sets;
+    // pacing pays once G no longer stays in the memory-side cache between its two reads; it needs every workgroup resident
+    // (one per CU) and whole groups of 16 blocks
+    a.paced = (p.ngrps == 1 && p.kgrps == 2 && p.sets % 8 == 0 && 2 * p.sets <= PACE_WGS && 2 * p.sets <= cu_count16() &&
+               M * ldg * 4 >= tn_pace_min_bytes()) ? 1 : 0;
     a.partial = (float*)ws;
     a.bias_partial = gbias ? (float*)((char*)ws + hgv_align256((size_t)p.ngrps * p.kgrps * p.sets * T16_SET_FLOATS * 4)) : nullptr;
     const size_t lds = 2 * T16_BUF;

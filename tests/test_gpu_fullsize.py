@@ -104,6 +104,30 @@ def test_two_source_product_rows_do_not_depend_on_the_row_count(big):
             assert torch.equal(part, full[lo:hi])
 
 
+def test_two_source_weight_gradient_is_reproducible_at_full_size(big):
+    """At this size the two workgroups that reduce one row slice against the two weight halves are placed on one XCD
+    and kept in step (they read the same rows of the gradient).  Which of them runs ahead varies from launch to
+    launch; the sums must not: two launches agree bit for bit, and a gradient with three quarters of its entries zero
+    (the state behind relu and dropout) is still the float64 product."""
+    from hgvae_amd import functional as Fn
+    _, _, x, gen = big
+    xb = torch.randn(N, H, device=DEV, generator=gen)
+    gout = torch.randn(N, H, device=DEV, generator=gen)
+    gout = gout * (torch.rand(N, H, device=DEV, generator=gen) < 0.25)
+    grads = []
+    for _ in range(2):
+        wa = (torch.randn(H, H, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5)) * 0.1).requires_grad_(True)
+        wb = (torch.randn(H, H, device=DEV, generator=torch.Generator(device=DEV).manual_seed(6)) * 0.1).requires_grad_(True)
+        bias = torch.zeros(H, device=DEV, requires_grad=True)
+        Fn.dual_linear(x, wa, xb, wb, bias).backward(gout)
+        grads.append((wa.grad.clone(), wb.grad.clone(), bias.grad.clone()))
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    assert rel(grads[0][0], gout.double().t() @ x.double()) <= 1e-5
+    assert rel(grads[0][1], gout.double().t() @ xb.double()) <= 1e-5
+    assert rel(grads[0][2], gout.double().sum(0)) <= 1e-5
+
+
 def test_relu_dropout_batchnorm_at_full_size(big):
     from hgvae_amd import functional as Fn
     from hgvae_amd.noise import NoiseTape, use_noise

@@ -14,10 +14,15 @@ int main(int argc, char** argv) {
     const int64_t lda = (K1 + 3) / 4 * 4, ldb = (K2 + 3) / 4 * 4, ldc = (N + 3) / 4 * 4;
     std::vector<float> h((size_t)M * (lda > ldc ? (lda > ldb ? lda : ldb) : (ldc > ldb ? ldc : ldb)) + 1024);
     for (auto& v : h) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+    // SPARSE=p: a fraction p of G is zero, as in a gradient behind relu and dropout (drawn before the first HIP call: the
+    // runtime's own threads use rand() as well)
+    const double sp = getenv("SPARSE") ? atof(getenv("SPARSE")) : 0.0;
+    std::vector<float> hg(h.begin(), h.begin() + (size_t)M * ldc);
+    if (sp > 0) for (auto& v : hg) if ((double)rand() / RAND_MAX < sp) v = 0.f;
     float *A1, *A2 = nullptr, *W, *C, *bias, *G, *GW1, *GW2;
     hipMalloc(&A1, (size_t)M * lda * 4); hipMemcpy(A1, h.data(), (size_t)M * lda * 4, hipMemcpyHostToDevice);
     if (K2) { hipMalloc(&A2, (size_t)M * ldb * 4); hipMemcpy(A2, h.data(), (size_t)M * ldb * 4, hipMemcpyHostToDevice); }
-    hipMalloc(&G, (size_t)M * ldc * 4); hipMemcpy(G, h.data(), (size_t)M * ldc * 4, hipMemcpyHostToDevice);
+    hipMalloc(&G, (size_t)M * ldc * 4); hipMemcpy(G, hg.data(), (size_t)M * ldc * 4, hipMemcpyHostToDevice);
     hipMalloc(&W, (size_t)N * (K1 + K2) * 4); hipMemcpy(W, h.data(), (size_t)N * (K1 + K2) * 4, hipMemcpyHostToDevice);
     hipMalloc(&bias, N * 4); hipMemcpy(bias, h.data(), N * 4, hipMemcpyHostToDevice);
     hipMalloc(&C, (size_t)M * ldc * 4);
@@ -45,6 +50,11 @@ int main(int argc, char** argv) {
         hipMemcpy(out.data(), C, out.size() * 4, hipMemcpyDeviceToHost);
         for (int64_t r = 0; r < M; ++r)
             for (int c = 0; c < N; ++c) { hash ^= out[(size_t)r * ldc + c]; hash *= 1099511628211ull; }
+    }
+    if (do_tn) {
+        std::vector<unsigned> out((size_t)N * (K1 + K2));
+        hipMemcpy(out.data(), GW1, out.size() * 4, hipMemcpyDeviceToHost);
+        for (unsigned v : out) { hash ^= v; hash *= 1099511628211ull; }
     }
     const double fl = 2.0 * M * (K1 + K2) * N;
     printf("%-14s %s M=%lld K=%d+%d N=%d: avg %.1f us  best %.1f us  %.1f TF/s  out %016llx\n", tag, do_tn ? "TN" : "NT", (long long)M, K1, K2, N,
