@@ -21,3 +21,15 @@ def test_two_rank_averaged_gradients_match_two_chunk_emulation():
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["ok"] and out["world"] == 2 and out["rank0_bn_buffers_equal_single_process"], out
+
+
+def test_flat_bucket_through_rccl_on_one_rank():
+    """The RCCL backend itself (not gloo): initialise, all-reduce the flat gradient bucket in place, device-pinned
+    barrier, clean shutdown - in a process of its own so that the group does not outlive the test."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, os.path.join(HERE, "rccl_worker.py")], env=env, capture_output=True, text=True,
+                         timeout=110)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ok"] and out["backend"] == "nccl", out
