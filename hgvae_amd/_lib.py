@@ -33,6 +33,10 @@ SIGNATURES = {
     "hgv_bn_act_eval": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _vp]),
     "hgv_bn_act_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _vp,
                                  _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "hgv_bn_act_fwd2": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _f32, _u64, _u64, _u64, _vp, _vp, _vp, _f32, _vp, _vp,
+                                  _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "hgv_bn_act_bwd2": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _u64, _u64, _u64,
+                                  _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "hgv_exclusive_scan_ws": (_sz, [_i64]),
     "hgv_exclusive_scan_i32": (C.c_int, [_vp, _vp, _i64, _vp, _sz, _vp]),
     "hgv_gat_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _f32, _f32, _vp, _u64, _u64, _vp, _vp,

@@ -30,6 +30,7 @@ struct EpArgs {
     float p; float scale; uint32_t thresh;   // Philox: keep iff 16 random bits >= thresh = round(p * 65536)
     const uint8_t* mask;             // [N, H] contiguous
     uint64_t seed, offset;
+    uint64_t offset2;                // Philox offset of the second noise set (kernels instantiated for two sets)
     const uint64_t* offset_dev;      // optional device word added to offset (advanced once per step under graph replay)
 };
 
@@ -62,7 +63,7 @@ __device__ __forceinline__ void st4(float* base, int64_t ld, int64_t row, int c0
 }
 
 // keep-multipliers (0 or scale) for the two 4-column chunks (cp, cp + CP) of chunk pair cp
-__device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, float4 (&k)[2]) {
+__device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, float4 (&k)[2], int set = 0) {
     k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
     if (a.mode == 1) {
 #pragma unroll
@@ -76,7 +77,7 @@ __device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, floa
         }
     } else if (a.mode == 2) {
         const HgvPhilox ph(a.seed);
-        const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
+        const uint64_t off = (set ? a.offset2 : a.offset) + (a.offset_dev ? a.offset_dev[0] : 0ull);
         const uint4 r = ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)cp << 8),
                                      (uint32_t)off, (uint32_t)(off >> 32));
         const uint32_t T = a.thresh;
@@ -96,9 +97,9 @@ __device__ __forceinline__ void chunk_cols(const EpArgs& a, int cp, int (&c)[2])
 
 // d = dropout(relu(y)) for the two chunks of pair cp in one row; yv holds the loaded y values
 __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, const float4 (&yv)[2], float4 (&d)[2],
-                                         float4* keep_out = nullptr) {
+                                         float4* keep_out = nullptr, int set = 0) {
     float4 k[2];
-    if (a.mode != 0) keep8(a, row, cp, k);
+    if (a.mode != 0) keep8(a, row, cp, k, set);
     else k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -112,8 +113,9 @@ __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, c
 
 constexpr int EP_PIVOT_ROWS = 8;
 
-// partial layout: [block][2][Hp] = (mean_b, M2_b), Hp = CH*4
-template <bool VEC>
+// partial layout: [set][block][2][Hp] = (mean_b, M2_b), Hp = CH*4.  NS = 2: two noise sets (Philox offsets a.offset and
+// a.offset2) over one read of y - the statistics of two dropout draws of the same pre-activation.
+template <bool VEC, int NS>
 __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial) {
     __shared__ float4 sh[512];
     __shared__ float4 sh2[512];
@@ -128,75 +130,87 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     // shift of the sums: the column mean over the block's first EP_PIVOT_ROWS rows.  A single row as the shift can sit
     // several standard deviations from the mean, and S2 - S1^2/n then loses that factor squared in fp32 - visible when
     // a batch has only a few hundred rows in all; any shift within about one standard deviation is as good as the mean.
-    {
+    float4 s[NS][2], S1[NS][2], S2[NS][2];
+#pragma unroll
+    for (int set = 0; set < NS; ++set) {
+        s[set][0] = s[set][1] = S1[set][0] = S1[set][1] = S2[set][0] = S2[set][1] = make_float4(0, 0, 0, 0);
         float4 d[2];
         d[0] = d[1] = make_float4(0, 0, 0, 0);
         if (active && rsub < EP_PIVOT_ROWS && r0 + rsub < r1) {
             float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, r0 + rsub, cc[1], a.H);
-            apply_d2(a, r0 + rsub, cp, yv, d);
+            apply_d2(a, r0 + rsub, cp, yv, d, nullptr, set);
         }
+        if (set > 0) __syncthreads();               // the previous set's pivot rows have been read
         if (rsub < EP_PIVOT_ROWS) { sh[2 * t] = d[0]; sh[2 * t + 1] = d[1]; }
+        __syncthreads();
+        if (active) {
+            const int cnt = (int)min((int64_t)min(a.RPB, EP_PIVOT_ROWS), r1 - r0);
+            for (int r = 0; r < cnt; ++r) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 u = sh[2 * (r * a.CP + cp) + h];
+                    s[set][h].x += u.x; s[set][h].y += u.y; s[set][h].z += u.z; s[set][h].w += u.w;
+                }
+            }
+            const float inv = 1.f / (float)cnt;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { s[set][h].x *= inv; s[set][h].y *= inv; s[set][h].z *= inv; s[set][h].w *= inv; }
+        }
     }
-    __syncthreads();
-    float4 s[2], S1[2], S2[2];
-    s[0] = s[1] = S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
     if (active) {
-        const int cnt = (int)min((int64_t)min(a.RPB, EP_PIVOT_ROWS), r1 - r0);
-        for (int r = 0; r < cnt; ++r) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float4 u = sh[2 * (r * a.CP + cp) + h];
-                s[h].x += u.x; s[h].y += u.y; s[h].z += u.z; s[h].w += u.w;
-            }
-        }
-        const float inv = 1.f / (float)cnt;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) { s[h].x *= inv; s[h].y *= inv; s[h].z *= inv; s[h].w *= inv; }
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-            float4 yv[2], d[2];
+            float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-            apply_d2(a, row, cp, yv, d);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const float tx = d[h].x - s[h].x, ty = d[h].y - s[h].y, tz = d[h].z - s[h].z, tw = d[h].w - s[h].w;
-                S1[h].x += tx; S1[h].y += ty; S1[h].z += tz; S1[h].w += tw;
-                S2[h].x += tx * tx; S2[h].y += ty * ty; S2[h].z += tz * tz; S2[h].w += tw * tw;
+            for (int set = 0; set < NS; ++set) {
+                float4 d[2];
+                apply_d2(a, row, cp, yv, d, nullptr, set);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float tx = d[h].x - s[set][h].x, ty = d[h].y - s[set][h].y, tz = d[h].z - s[set][h].z, tw = d[h].w - s[set][h].w;
+                    S1[set][h].x += tx; S1[set][h].y += ty; S1[set][h].z += tz; S1[set][h].w += tw;
+                    S2[set][h].x += tx * tx; S2[set][h].y += ty * ty; S2[set][h].z += tz * tz; S2[set][h].w += tw * tw;
+                }
             }
         }
     }
-    __syncthreads();
-    sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
-    __syncthreads();
-    if (active && rsub == 0) {
-        // the row slots' sums are added in fp64 (up to 256 of them for narrow rows), and so is M2 = S2 - S1^2 / n
-        double D1[2][4], D2[2][4];
+    const int Hp = a.CH * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            D1[h][0] = S1[h].x; D1[h][1] = S1[h].y; D1[h][2] = S1[h].z; D1[h][3] = S1[h].w;
-            D2[h][0] = S2[h].x; D2[h][1] = S2[h].y; D2[h][2] = S2[h].z; D2[h][3] = S2[h].w;
-        }
-        for (int r = 1; r < a.RPB; ++r) {
+    for (int set = 0; set < NS; ++set) {
+        __syncthreads();
+        sh[2 * t] = S1[set][0]; sh[2 * t + 1] = S1[set][1]; sh2[2 * t] = S2[set][0]; sh2[2 * t + 1] = S2[set][1];
+        __syncthreads();
+        if (active && rsub == 0) {
+            // the row slots' sums are added in fp64 (up to 256 of them for narrow rows), and so is M2 = S2 - S1^2 / n
+            double D1[2][4], D2[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
-                D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
-                D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
+                D1[h][0] = S1[set][h].x; D1[h][1] = S1[set][h].y; D1[h][2] = S1[set][h].z; D1[h][3] = S1[set][h].w;
+                D2[h][0] = S2[set][h].x; D2[h][1] = S2[set][h].y; D2[h][2] = S2[set][h].z; D2[h][3] = S2[set][h].w;
             }
-        }
-        const double n = (double)(r1 - r0);
-        const int Hp = a.CH * 4;
-        for (int h = 0; h < nh; ++h) {
-            const float sv[4] = {s[h].x, s[h].y, s[h].z, s[h].w};
-            float mv[4], qv[4];
+            for (int r = 1; r < a.RPB; ++r) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                mv[e] = (float)((double)sv[e] + D1[h][e] / n);
-                qv[e] = (float)(D2[h][e] - D1[h][e] * D1[h][e] / n);
+                for (int h = 0; h < 2; ++h) {
+                    const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
+                    D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
+                    D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
+                }
             }
-            const int c0 = (cp + h * a.CP) * 4;
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+            const double n = (double)(r1 - r0);
+            float* dst = partial + (int64_t)set * gridDim.x * 2 * Hp;
+            for (int h = 0; h < nh; ++h) {
+                const float sv[4] = {s[set][h].x, s[set][h].y, s[set][h].z, s[set][h].w};
+                float mv[4], qv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mv[e] = (float)((double)sv[e] + D1[h][e] / n);
+                    qv[e] = (float)(D2[h][e] - D1[h][e] * D1[h][e] / n);
+                }
+                const int c0 = (cp + h * a.CP) * 4;
+                *reinterpret_cast<float4*>(dst + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                *reinterpret_cast<float4*>(dst + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+            }
         }
     }
 }
@@ -236,49 +250,55 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
                                                            float* __restrict__ running_var,
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_rstd,
-                                                           int64_t* __restrict__ num_batches_tracked) {
+                                                           int64_t* __restrict__ num_batches_tracked, int nsets) {
     __shared__ double sh[FIN_SL][17];
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += nsets;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     const bool ok = c < H;
-    double a1 = 0.0, a2 = 0.0, pivot = 0.0;
-    if (ok) {
-        pivot = (double)partial[c];
-        const double n_full = (double)rows_per_block;
-        const double n_tail = (double)(N - (int64_t)(nblocks - 1) * rows_per_block);
-        // batches of 8 independent loads (clamped index, zero weight past the end) before the fp64 chain
-        for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
-            float m[8], q[8];
+    // sets one after the other: the running statistics take the momentum update of set 0, then that of set 1, as two
+    // forward calls would apply them; save_mean / save_rstd of set s start at element s * H
+    for (int set = 0; set < nsets; ++set) {
+        const float* part = partial + (int64_t)set * nblocks * 2 * Hp;
+        double a1 = 0.0, a2 = 0.0, pivot = 0.0;
+        if (ok) {
+            pivot = (double)part[c];
+            const double n_full = (double)rows_per_block;
+            const double n_tail = (double)(N - (int64_t)(nblocks - 1) * rows_per_block);
+            // batches of 8 independent loads (clamped index, zero weight past the end) before the fp64 chain
+            for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
+                float m[8], q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = min(b0 + u * FIN_SL, nblocks - 1);
-                m[u] = partial[((int64_t)b * 2) * Hp + c];
-                q[u] = partial[((int64_t)b * 2 + 1) * Hp + c];
-            }
+                for (int u = 0; u < 8; ++u) {
+                    const int b = min(b0 + u * FIN_SL, nblocks - 1);
+                    m[u] = part[((int64_t)b * 2) * Hp + c];
+                    q[u] = part[((int64_t)b * 2 + 1) * Hp + c];
+                }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = b0 + u * FIN_SL;
-                const double nb = b >= nblocks ? 0.0 : (b == nblocks - 1 ? n_tail : n_full);
-                const double d = (double)m[u] - pivot;
-                a1 += nb * d;
-                a2 += (b < nblocks ? (double)q[u] : 0.0) + nb * d * d;
+                for (int u = 0; u < 8; ++u) {
+                    const int b = b0 + u * FIN_SL;
+                    const double nb = b >= nblocks ? 0.0 : (b == nblocks - 1 ? n_tail : n_full);
+                    const double d = (double)m[u] - pivot;
+                    a1 += nb * d;
+                    a2 += (b < nblocks ? (double)q[u] : 0.0) + nb * d * d;
+                }
             }
         }
-    }
-    const double s1 = fin_tree(sh, sl, cl, a1);
-    const double s2 = fin_tree(sh, sl, cl, a2);
-    if (sl != 0 || !ok) return;
-    const double mean = pivot + s1 / (double)N;
-    double m2 = s2 - s1 * s1 / (double)N;
-    if (m2 < 0.0) m2 = 0.0;
-    const double var = m2 / (double)N;
-    save_mean[c] = (float)mean;
-    save_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    if (running_var) {
-        const double unb = N > 1 ? m2 / (double)(N - 1) : var;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+        const double s1 = fin_tree(sh, sl, cl, a1);
+        const double s2 = fin_tree(sh, sl, cl, a2);
+        if (sl == 0 && ok) {
+            const double mean = pivot + s1 / (double)N;
+            double m2 = s2 - s1 * s1 / (double)N;
+            if (m2 < 0.0) m2 = 0.0;
+            const double var = m2 / (double)N;
+            save_mean[set * H + c] = (float)mean;
+            save_rstd[set * H + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            if (running_var) {
+                const double unb = N > 1 ? m2 / (double)(N - 1) : var;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+            }
+        }
     }
 }
 
@@ -286,6 +306,8 @@ struct NormArgs {
     const float* mean; const float* rstd_or_var; int rstd_is_var; float eps;
     const float* gamma; const float* beta;
     float* out; int64_t ldo;
+    float* out2;                     // two noise sets: output of the second set (same leading dimension); its statistics
+                                     // follow the first set's at element H of mean / rstd_or_var
 };
 
 __device__ __forceinline__ float4 ldcol4(const float* p, int c0, int H, float fill) {
@@ -295,7 +317,7 @@ __device__ __forceinline__ float4 ldcol4(const float* p, int c0, int H, float fi
     return v;
 }
 
-template <bool VEC>
+template <bool VEC, int NS>
 __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs n) {
     const int t = threadIdx.x;
     if (t >= a.RPB * a.CP) return;
@@ -303,31 +325,38 @@ __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs
     const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    float4 mu[2], rs[2], ga[2], be[2];
+    float4 mu[NS][2], rs[NS][2], ga[2], be[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c0 = (cp + h * a.CP) * 4;
-        mu[h] = ldcol4(n.mean, c0, a.H, 0.f);
-        rs[h] = ldcol4(n.rstd_or_var, c0, a.H, 1.f);
-        if (n.rstd_is_var) {
-            rs[h].x = 1.f / sqrtf(rs[h].x + n.eps); rs[h].y = 1.f / sqrtf(rs[h].y + n.eps);
-            rs[h].z = 1.f / sqrtf(rs[h].z + n.eps); rs[h].w = 1.f / sqrtf(rs[h].w + n.eps);
+#pragma unroll
+        for (int set = 0; set < NS; ++set) {
+            mu[set][h] = ldcol4(n.mean ? n.mean + set * a.H : nullptr, c0, a.H, 0.f);
+            rs[set][h] = ldcol4(n.rstd_or_var ? n.rstd_or_var + set * a.H : nullptr, c0, a.H, 1.f);
+            if (n.rstd_is_var) {
+                rs[set][h].x = 1.f / sqrtf(rs[set][h].x + n.eps); rs[set][h].y = 1.f / sqrtf(rs[set][h].y + n.eps);
+                rs[set][h].z = 1.f / sqrtf(rs[set][h].z + n.eps); rs[set][h].w = 1.f / sqrtf(rs[set][h].w + n.eps);
+            }
         }
         ga[h] = ldcol4(n.gamma, c0, a.H, 1.f); be[h] = ldcol4(n.beta, c0, a.H, 0.f);
     }
     int cc[2];
     chunk_cols(a, cp, cc);
     for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-        float4 yv[2], d[2];
+        float4 yv[2];
         yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-        apply_d2(a, row, cp, yv, d);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h < nh) {
-                float4 o;
-                o.x = (d[h].x - mu[h].x) * rs[h].x * ga[h].x + be[h].x; o.y = (d[h].y - mu[h].y) * rs[h].y * ga[h].y + be[h].y;
-                o.z = (d[h].z - mu[h].z) * rs[h].z * ga[h].z + be[h].z; o.w = (d[h].w - mu[h].w) * rs[h].w * ga[h].w + be[h].w;
-                st4<VEC>(n.out, n.ldo, row, (cp + h * a.CP) * 4, a.H, o);
+        for (int set = 0; set < NS; ++set) {
+            float4 d[2];
+            apply_d2(a, row, cp, yv, d, nullptr, set);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h < nh) {
+                    float4 o;
+                    o.x = (d[h].x - mu[set][h].x) * rs[set][h].x * ga[h].x + be[h].x; o.y = (d[h].y - mu[set][h].y) * rs[set][h].y * ga[h].y + be[h].y;
+                    o.z = (d[h].z - mu[set][h].z) * rs[set][h].z * ga[h].z + be[h].z; o.w = (d[h].w - mu[set][h].w) * rs[set][h].w * ga[h].w + be[h].w;
+                    st4<VEC>(set ? n.out2 : n.out, n.ldo, row, (cp + h * a.CP) * 4, a.H, o);
+                }
             }
         }
     }
@@ -338,24 +367,30 @@ struct BwdArgs {
     const float* g; int64_t ldg;
     const float* g2; int64_t ldg2;   // optional second incoming gradient (the output had two consumers): g + g2 is used
     const float* mean; const float* rstd; const float* gamma;
-    const float* sums;   // [2][Hp]: sum g, sum g*xhat (apply pass only)
+    const float* sums;   // [set][2][Hp]: sum g, sum g*xhat (apply pass only)
     float* dy; int64_t lddy;
+    // two noise sets: the incoming gradients of the second set's output (h2 nullable); its mean / rstd follow the
+    // first set's at element H; dy receives the sum of the two sets' input gradients
+    const float* h; int64_t ldh;
+    const float* h2; int64_t ldh2;
 };
 
-// incoming gradient chunk: g (+ g2 when the forward output fed two consumers)
+// incoming gradient chunk of a set: g (+ g2 when the forward output fed two consumers)
 template <bool VEC>
-__device__ __forceinline__ float4 ldg4(const BwdArgs& b, int64_t row, int c0, int H) {
-    float4 v = ld4<VEC>(b.g, b.ldg, row, c0, H);
-    if (b.g2) {
-        const float4 w = ld4<VEC>(b.g2, b.ldg2, row, c0, H);
+__device__ __forceinline__ float4 ldg4(const BwdArgs& b, int64_t row, int c0, int H, int set = 0) {
+    const float* p = set ? b.h : b.g; const int64_t ld = set ? b.ldh : b.ldg;
+    const float* p2 = set ? b.h2 : b.g2; const int64_t ld2 = set ? b.ldh2 : b.ldg2;
+    float4 v = ld4<VEC>(p, ld, row, c0, H);
+    if (p2) {
+        const float4 w = ld4<VEC>(p2, ld2, row, c0, H);
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
     }
     return v;
 }
 
-// partial layout: [block][2][Hp] = (sum g, sum g*xhat)
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdArgs b, float* __restrict__ partial) {
+// partial layout: [set][block][2][Hp] = (sum g, sum g*xhat)
+template <bool VEC, int NS>
+__global__ __launch_bounds__(256, 4) void k_ep_bwd_stats(const EpArgs a, const BwdArgs b, float* __restrict__ partial) {
     __shared__ float4 sh[512];
     __shared__ float4 sh2[512];
     const int t = threadIdx.x;
@@ -364,144 +399,210 @@ __global__ __launch_bounds__(256) void k_ep_bwd_stats(const EpArgs a, const BwdA
     const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    float4 S1[2], S2[2];
-    S1[0] = S1[1] = S2[0] = S2[1] = make_float4(0, 0, 0, 0);
-    if (active) {
-        float4 mu[2], rs[2];
+    float4 S1[NS][2], S2[NS][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            mu[h] = ldcol4(b.mean, (cp + h * a.CP) * 4, a.H, 0.f);
-            rs[h] = ldcol4(b.rstd, (cp + h * a.CP) * 4, a.H, 0.f);
+    for (int set = 0; set < NS; ++set) S1[set][0] = S1[set][1] = S2[set][0] = S2[set][1] = make_float4(0, 0, 0, 0);
+    // NS = 2: mean and rstd of both sets sit in LDS ([set][2][Hp], in sh2 until the sums need it) and are fetched inside
+    // the row loop; as registers they cost the fourth workgroup per CU (see k_ep_bwd_apply)
+    float* cst = reinterpret_cast<float*>(sh2);
+    if (NS == 2) {
+        const int Hp = a.CH * 4;
+        for (int i = t; i < 2 * 2 * Hp; i += 256) {
+            const int set = i / (2 * Hp), arr = (i / Hp) & 1, c = i % Hp;
+            cst[i] = c < a.H ? (arr ? b.rstd : b.mean)[set * a.H + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float4 mu[NS][2], rs[NS][2];
+        if (NS == 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                mu[0][h] = ldcol4(b.mean, (cp + h * a.CP) * 4, a.H, 0.f);
+                rs[0][h] = ldcol4(b.rstd, (cp + h * a.CP) * 4, a.H, 0.f);
+            }
         }
         int cc[2];
         chunk_cols(a, cp, cc);
         for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-            float4 yv[2], gv[2], d[2];
+            float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-            gv[0] = ldg4<VEC>(b, row, cc[0], a.H); gv[1] = ldg4<VEC>(b, row, cc[1], a.H);
-            apply_d2(a, row, cp, yv, d);
+            int opaque = 0;
+            if (NS == 2) asm volatile("" : "+v"(opaque));        // keeps the constant fetches below inside the loop
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                {
+            for (int set = 0; set < NS; ++set) {
+                float4 gv[2], d[2];
+                gv[0] = ldg4<VEC>(b, row, cc[0], a.H, set); gv[1] = ldg4<VEC>(b, row, cc[1], a.H, set);
+                apply_d2(a, row, cp, yv, d, nullptr, set);
+                if (NS == 2) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float* base = cst + opaque + set * 2 * (a.CH * 4) + cc[h];
+                        mu[set][h] = *reinterpret_cast<const float4*>(base);
+                        rs[set][h] = *reinterpret_cast<const float4*>(base + a.CH * 4);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
                     const float4 g = gv[h];
-                    S1[h].x += g.x; S1[h].y += g.y; S1[h].z += g.z; S1[h].w += g.w;
-                    S2[h].x += g.x * ((d[h].x - mu[h].x) * rs[h].x); S2[h].y += g.y * ((d[h].y - mu[h].y) * rs[h].y);
-                    S2[h].z += g.z * ((d[h].z - mu[h].z) * rs[h].z); S2[h].w += g.w * ((d[h].w - mu[h].w) * rs[h].w);
+                    S1[set][h].x += g.x; S1[set][h].y += g.y; S1[set][h].z += g.z; S1[set][h].w += g.w;
+                    S2[set][h].x += g.x * ((d[h].x - mu[set][h].x) * rs[set][h].x); S2[set][h].y += g.y * ((d[h].y - mu[set][h].y) * rs[set][h].y);
+                    S2[set][h].z += g.z * ((d[h].z - mu[set][h].z) * rs[set][h].z); S2[set][h].w += g.w * ((d[h].w - mu[set][h].w) * rs[set][h].w);
                 }
             }
         }
     }
-    sh[2 * t] = S1[0]; sh[2 * t + 1] = S1[1]; sh2[2 * t] = S2[0]; sh2[2 * t + 1] = S2[1];
-    __syncthreads();
-    if (active && rsub == 0) {
-        double D1[2][4], D2[2][4];       // row slots added in fp64 (up to 256 of them for narrow rows)
+    const int Hp = a.CH * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            D1[h][0] = S1[h].x; D1[h][1] = S1[h].y; D1[h][2] = S1[h].z; D1[h][3] = S1[h].w;
-            D2[h][0] = S2[h].x; D2[h][1] = S2[h].y; D2[h][2] = S2[h].z; D2[h][3] = S2[h].w;
-        }
-        for (int r = 1; r < a.RPB; ++r) {
+    for (int set = 0; set < NS; ++set) {
+        if (set > 0 || NS == 2) __syncthreads();        // NS = 2: every thread is done with the constants held in sh2
+        sh[2 * t] = S1[set][0]; sh[2 * t + 1] = S1[set][1]; sh2[2 * t] = S2[set][0]; sh2[2 * t + 1] = S2[set][1];
+        __syncthreads();
+        if (active && rsub == 0) {
+            double D1[2][4], D2[2][4];       // row slots added in fp64 (up to 256 of them for narrow rows)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
-                D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
-                D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
+                D1[h][0] = S1[set][h].x; D1[h][1] = S1[set][h].y; D1[h][2] = S1[set][h].z; D1[h][3] = S1[set][h].w;
+                D2[h][0] = S2[set][h].x; D2[h][1] = S2[set][h].y; D2[h][2] = S2[set][h].z; D2[h][3] = S2[set][h].w;
             }
-        }
-        const int Hp = a.CH * 4;
-        for (int h = 0; h < nh; ++h) {
-            const int c0 = (cp + h * a.CP) * 4;
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) =
-                make_float4((float)D1[h][0], (float)D1[h][1], (float)D1[h][2], (float)D1[h][3]);
-            *reinterpret_cast<float4*>(partial + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) =
-                make_float4((float)D2[h][0], (float)D2[h][1], (float)D2[h][2], (float)D2[h][3]);
+            for (int r = 1; r < a.RPB; ++r) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 u = sh[2 * (r * a.CP + cp) + h], w = sh2[2 * (r * a.CP + cp) + h];
+                    D1[h][0] += u.x; D1[h][1] += u.y; D1[h][2] += u.z; D1[h][3] += u.w;
+                    D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
+                }
+            }
+            float* dst = partial + (int64_t)set * gridDim.x * 2 * Hp;
+            for (int h = 0; h < nh; ++h) {
+                const int c0 = (cp + h * a.CP) * 4;
+                *reinterpret_cast<float4*>(dst + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) =
+                    make_float4((float)D1[h][0], (float)D1[h][1], (float)D1[h][2], (float)D1[h][3]);
+                *reinterpret_cast<float4*>(dst + ((int64_t)blockIdx.x * 2 + 1) * Hp + c0) =
+                    make_float4((float)D2[h][0], (float)D2[h][1], (float)D2[h][2], (float)D2[h][3]);
+            }
         }
     }
 }
 
+// sums of set s at sums + s * 2 * Hp; dgamma / dbeta take set 0 as `accumulate` says and every further set added
 __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restrict__ partial, int nblocks, int H,
                                                          int Hp, float* __restrict__ sums,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                         int accumulate) {
+                                                         int accumulate, int nsets) {
     __shared__ double sh[FIN_SL][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < H) {
-        for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
-            float m[8], q[8];
+    for (int set = 0; set < nsets; ++set) {
+        const float* part = partial + (int64_t)set * nblocks * 2 * Hp;
+        double a1 = 0.0, a2 = 0.0;
+        if (c < H) {
+            for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
+                float m[8], q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int b = min(b0 + u * FIN_SL, nblocks - 1);
-                m[u] = partial[((int64_t)b * 2 + 0) * Hp + c];
-                q[u] = partial[((int64_t)b * 2 + 1) * Hp + c];
+                for (int u = 0; u < 8; ++u) {
+                    const int b = min(b0 + u * FIN_SL, nblocks - 1);
+                    m[u] = part[((int64_t)b * 2 + 0) * Hp + c];
+                    q[u] = part[((int64_t)b * 2 + 1) * Hp + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool in = b0 + u * FIN_SL < nblocks;
+                    a1 += in ? (double)m[u] : 0.0;
+                    a2 += in ? (double)q[u] : 0.0;
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = b0 + u * FIN_SL < nblocks;
-                a1 += in ? (double)m[u] : 0.0;
-                a2 += in ? (double)q[u] : 0.0;
+        }
+        const double s1 = fin_tree(sh, sl, cl, a1);
+        const double s2 = fin_tree(sh, sl, cl, a2);
+        if (sl == 0 && c < Hp) {
+            sums[set * 2 * Hp + c] = (float)s1;
+            sums[set * 2 * Hp + Hp + c] = (float)s2;
+            if (c < H) {
+                const bool add = accumulate || set > 0;
+                if (dbeta) dbeta[c] = add ? dbeta[c] + (float)s1 : (float)s1;
+                if (dgamma) dgamma[c] = add ? dgamma[c] + (float)s2 : (float)s2;
             }
         }
     }
-    const double s1 = fin_tree(sh, sl, cl, a1);
-    const double s2 = fin_tree(sh, sl, cl, a2);
-    if (sl != 0 || c >= Hp) return;
-    sums[c] = (float)s1;
-    sums[Hp + c] = (float)s2;
-    if (c < H) {
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
-    }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_ep_bwd_apply(const EpArgs a, const BwdArgs b) {
+// NS = 2 keeps the per-column constants of both sets (mean, rstd, sum g, sum g*xhat) in LDS and fetches them inside
+// the row loop: as registers they push the kernel past 128 VGPRs, to three workgroups per CU and a second, third-full
+// round of the 1024 row ranges (launch with 2 * 4 * Hp floats of dynamic LDS; none for NS = 1).
+template <bool VEC, int NS>
+__global__ __launch_bounds__(256, 4) void k_ep_bwd_apply(const EpArgs a, const BwdArgs b) {
+    extern __shared__ __attribute__((aligned(16))) float cst[];
     const int t = threadIdx.x;
+    const int Hp = a.CH * 4;
+    if (NS == 2) {
+        for (int i = t; i < 2 * 4 * Hp; i += 256) {
+            const int set = i / (4 * Hp), arr = (i / Hp) & 3, c = i % Hp;
+            cst[i] = arr == 0 ? (c < a.H ? b.mean[set * a.H + c] : 0.f) : arr == 1 ? (c < a.H ? b.rstd[set * a.H + c] : 0.f)
+                   : b.sums[set * 2 * Hp + (arr - 2) * Hp + c];
+        }
+        __syncthreads();
+    }
     if (t >= a.RPB * a.CP) return;
     const int rsub = t / a.CP, cp = t - rsub * a.CP;
     const int nh = cp + a.CP < a.CH ? 2 : 1;
     const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
     const int64_t r1 = min(a.N, r0 + a.rows_per_block);
-    const int Hp = a.CH * 4;
     const float invn = 1.f / (float)a.N;
-    float4 mu[2], rs[2], ga[2], sg[2], sgx[2];
+    float4 mu[NS][2], rs[NS][2], ga[2], sg[NS][2], sgx[NS][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c0 = (cp + h * a.CP) * 4;
-        mu[h] = ldcol4(b.mean, c0, a.H, 0.f); rs[h] = ldcol4(b.rstd, c0, a.H, 0.f); ga[h] = ldcol4(b.gamma, c0, a.H, 1.f);
-        sg[h] = sgx[h] = make_float4(0, 0, 0, 0);
-        if (h < nh) {
-            sg[h] = *reinterpret_cast<const float4*>(b.sums + c0);
-            sgx[h] = *reinterpret_cast<const float4*>(b.sums + Hp + c0);
+        ga[h] = ldcol4(b.gamma, c0, a.H, 1.f);
+        if (NS == 1) {
+            mu[0][h] = ldcol4(b.mean, c0, a.H, 0.f); rs[0][h] = ldcol4(b.rstd, c0, a.H, 0.f);
+            sg[0][h] = sgx[0][h] = make_float4(0, 0, 0, 0);
+            if (h < nh) {
+                sg[0][h] = *reinterpret_cast<const float4*>(b.sums + c0);
+                sgx[0][h] = *reinterpret_cast<const float4*>(b.sums + Hp + c0);
+            }
         }
     }
     int cc[2];
     chunk_cols(a, cp, cc);
     for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
-        float4 d[2], y[2], k[2], gv[2];
+        float4 y[2], o[2];
         y[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); y[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
-        gv[0] = ldg4<VEC>(b, row, cc[0], a.H); gv[1] = ldg4<VEC>(b, row, cc[1], a.H);
-        apply_d2(a, row, cp, y, d, k);
+        int opaque = 0;
+        if (NS == 2) asm volatile("" : "+v"(opaque));            // keeps the constant fetches below inside the loop
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (h < nh) {
-                const int c0 = cc[h];
+        for (int set = 0; set < NS; ++set) {
+            float4 d[2], k[2], gv[2];
+            gv[0] = ldg4<VEC>(b, row, cc[0], a.H, set); gv[1] = ldg4<VEC>(b, row, cc[1], a.H, set);
+            apply_d2(a, row, cp, y, d, k, set);
+            if (NS == 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float* base = cst + opaque + set * 4 * Hp + cc[h];
+                    mu[set][h] = *reinterpret_cast<const float4*>(base);
+                    rs[set][h] = *reinterpret_cast<const float4*>(base + Hp);
+                    sg[set][h] = *reinterpret_cast<const float4*>(base + 2 * Hp);
+                    sgx[set][h] = *reinterpret_cast<const float4*>(base + 3 * Hp);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
                 const float4 g = gv[h];
-                float4 o;
 #define HGV_EP_BWD(f)                                                                              \
                 {                                                                                  \
-                    const float xh = (d[h].f - mu[h].f) * rs[h].f;                                 \
-                    float dd = ga[h].f * rs[h].f * (g.f - sg[h].f * invn - xh * (sgx[h].f * invn)); \
+                    const float xh = (d[h].f - mu[set][h].f) * rs[set][h].f;                       \
+                    float dd = ga[h].f * rs[set][h].f * (g.f - sg[set][h].f * invn - xh * (sgx[set][h].f * invn)); \
                     dd *= k[h].f;                                                                  \
                     if (a.relu && !(y[h].f > 0.f)) dd = 0.f;                                       \
-                    o.f = dd;                                                                      \
+                    o[h].f = set ? o[h].f + dd : dd;                                               \
                 }
                 HGV_EP_BWD(x) HGV_EP_BWD(y) HGV_EP_BWD(z) HGV_EP_BWD(w)
 #undef HGV_EP_BWD
-                st4<VEC>(b.dy, b.lddy, row, c0, a.H, o);
             }
         }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h < nh) st4<VEC>(b.dy, b.lddy, row, cc[h], a.H, o[h]);
     }
 }
 
@@ -515,7 +616,7 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.y = y; a.ldy = ldy; a.N = N; a.H = H; a.CH = (H + 3) / 4; a.CP = (a.CH + 1) / 2; a.RPB = 256 / a.CP;
     a.relu = relu; a.p = p; a.scale = 1.0f / (float)(1.0 - (double)p);
     a.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
-    a.mask = mask; a.seed = seed; a.offset = offset; a.offset_dev = offset_dev;
+    a.mask = mask; a.seed = seed; a.offset = offset; a.offset2 = 0; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
     // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread
     int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 4);
@@ -531,23 +632,28 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
 extern "C" size_t hgv_bn_act_ws(int64_t N, int H) {
     (void)N;
     const size_t Hp = (size_t)((H + 3) / 4) * 4;
-    return hgv_align256(2048 * 2 * Hp * sizeof(float)) + hgv_align256(2 * Hp * sizeof(float));
+    return hgv_align256(2048 * 2 * Hp * sizeof(float)) + hgv_align256(4 * Hp * sizeof(float));      // partials of two sets of <= 1024 row ranges; sums of two sets
 }
 
 namespace {
-// Launch sequence of the training-mode forward; partial = [nblocks <= 1024][2][Hp] floats of scratch.
+// Launch sequence of the training-mode forward; partial = [nsets][nblocks <= 1024][2][Hp] floats of scratch.  With
+// nsets = 2 (a.offset / a.offset2, Philox noise, 16-byte rows) out2 receives the second set and save_mean / save_rstd
+// hold [2][H].
 int bn_act_fwd_launch(const EpArgs& a, int nb, const float* gamma, const float* beta, float eps, float* running_mean,
                       float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean, float* save_rstd,
-                      float* out, int64_t ldo, float* partial, hipStream_t stream) {
+                      float* out, int64_t ldo, float* partial, hipStream_t stream, int nsets = 1, float* out2 = nullptr) {
     const int Hp = a.CH * 4;
-    const bool vec = vec4_ok(a.y, a.ldy, Hp) && vec4_ok(out, ldo, Hp);
-    if (vec) hipLaunchKernelGGL(k_ep_stats<true>, dim3(nb), dim3(256), 0, stream, a, partial);
-    else hipLaunchKernelGGL(k_ep_stats<false>, dim3(nb), dim3(256), 0, stream, a, partial);
+    const bool vec = vec4_ok(a.y, a.ldy, Hp) && vec4_ok(out, ldo, Hp) && vec4_ok(out2, ldo, Hp);
+    HGV_REQUIRE(nsets == 1 || vec, HGV_EUNSUPPORTED, "bn_act_fwd2: rows must be 16-byte aligned with padded leading dimensions");
+    if (nsets == 2) hipLaunchKernelGGL((k_ep_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, partial);
+    else if (vec) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
     hipLaunchKernelGGL(k_ep_stats_finalize, dim3((a.H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
-                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked);
-    NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo};
-    if (vec) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
-    else hipLaunchKernelGGL(k_ep_apply<false>, dim3(nb), dim3(256), 0, stream, a, n);
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, nsets);
+    NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo, out2};
+    if (nsets == 2) hipLaunchKernelGGL((k_ep_apply<true, 2>), dim3(nb), dim3(256), 0, stream, a, n);
+    else if (vec) hipLaunchKernelGGL((k_ep_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, n);
+    else hipLaunchKernelGGL((k_ep_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, n);
     HGV_CHECK_LAUNCH("bn_act_fwd");
     return HGV_OK;
 }
@@ -634,9 +740,9 @@ extern "C" int hgv_bn_act_eval(const float* y, int64_t ldy, int64_t N, int H, in
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(out && ldo >= H && running_mean && running_var, HGV_EINVAL, "bn_act_eval: null/short buffer");
     const int Hp = a.CH * 4;
-    NormArgs n{running_mean, running_var, 1, eps, gamma, beta, out, ldo};
-    if (vec4_ok(y, ldy, Hp) && vec4_ok(out, ldo, Hp)) hipLaunchKernelGGL(k_ep_apply<true>, dim3(nb), dim3(256), 0, stream, a, n);
-    else hipLaunchKernelGGL(k_ep_apply<false>, dim3(nb), dim3(256), 0, stream, a, n);
+    NormArgs n{running_mean, running_var, 1, eps, gamma, beta, out, ldo, nullptr};
+    if (vec4_ok(y, ldy, Hp) && vec4_ok(out, ldo, Hp)) hipLaunchKernelGGL((k_ep_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, n);
+    else hipLaunchKernelGGL((k_ep_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, n);
     HGV_CHECK_LAUNCH("bn_act_eval");
     return HGV_OK;
 }
@@ -658,13 +764,68 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int6
     const int Hp = a.CH * 4;
     float* partial = (float*)ws;
     float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
-    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy};
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, nullptr, 0, nullptr, 0};
     const bool vec = vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(dy, lddy, Hp);
-    if (vec) hipLaunchKernelGGL(k_ep_bwd_stats<true>, dim3(nb), dim3(256), 0, stream, a, b, partial);
-    else hipLaunchKernelGGL(k_ep_bwd_stats<false>, dim3(nb), dim3(256), 0, stream, a, b, partial);
-    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate);
-    if (vec) hipLaunchKernelGGL(k_ep_bwd_apply<true>, dim3(nb), dim3(256), 0, stream, a, b);
-    else hipLaunchKernelGGL(k_ep_bwd_apply<false>, dim3(nb), dim3(256), 0, stream, a, b);
+    if (vec) hipLaunchKernelGGL((k_ep_bwd_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+    else hipLaunchKernelGGL((k_ep_bwd_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 1);
+    if (vec) hipLaunchKernelGGL((k_ep_bwd_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, b);
+    else hipLaunchKernelGGL((k_ep_bwd_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd");
+    return HGV_OK;
+}
+
+// ---- two dropout draws of one pre-activation in one pass ------------------------------------------------------------
+// The reference encodes every batch twice per train step (gvae/gvae_skipcon.py:166-171); nothing stochastic precedes the
+// first convolution, so both passes apply relu -> Dropout -> BatchNorm1d (:105-107) to the SAME matrix y with different
+// masks.  These entry points do the work of two hgv_bn_act_fwd / hgv_bn_act_bwd calls over one read of y: outputs out
+// (Philox offset) and out2 (offset2), statistics save_mean / save_rstd = [2][H], the running statistics and
+// num_batches_tracked updated for the first draw and then for the second; backward: g / g2 are the incoming gradients
+// of out (g2 nullable), h / h2 those of out2 (h2 nullable), dy the SUM of the two input gradients, dgamma / dbeta the
+// sums over both draws.  Results are those of the two separate calls bit for bit.  Philox noise with p > 0 only
+// (explicit masks: two calls); buffers 16-byte aligned with leading dimensions that are multiples of 4.
+#define HGV_BN_PAIR_MAX_H 512      /* the backward kernels keep 4 * Hp column constants in an 8 KB LDS array */
+extern "C" int hgv_bn_act_fwd2(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, uint64_t seed,
+                               uint64_t offset, uint64_t offset2, const uint64_t* offset_dev, const float* gamma,
+                               const float* beta, float eps, float* running_mean, float* running_var, float momentum,
+                               int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* out, float* out2,
+                               int64_t ldo, void* ws, size_t ws_bytes, hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, y, ldy, N, H, relu, p, nullptr, seed, offset, offset_dev, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(p > 0.f, HGV_EINVAL, "bn_act_fwd2: two draws need p > 0");
+    HGV_REQUIRE(H <= HGV_BN_PAIR_MAX_H, HGV_EUNSUPPORTED, "bn_act_fwd2: H=%d exceeds %d (use two hgv_bn_act_fwd calls)", H, HGV_BN_PAIR_MAX_H);
+    HGV_REQUIRE(out && out2 && ldo >= H && save_mean && save_rstd && ws, HGV_EINVAL, "bn_act_fwd2: null/short buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_fwd2: workspace too small or misaligned");
+    a.offset2 = offset2;
+    return bn_act_fwd_launch(a, nb, gamma, beta, eps, running_mean, running_var, momentum, num_batches_tracked, save_mean,
+                             save_rstd, out, ldo, (float*)ws, stream, 2, out2);
+}
+
+extern "C" int hgv_bn_act_bwd2(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* h, int64_t ldh,
+                               const float* h2, int64_t ldh2, const float* y, int64_t ldy, int64_t N, int H, int relu,
+                               float p, uint64_t seed, uint64_t offset, uint64_t offset2, const uint64_t* offset_dev,
+                               const float* gamma, const float* save_mean, const float* save_rstd, float* dy,
+                               int64_t lddy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                               hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, y, ldy, N, H, relu, p, nullptr, seed, offset, offset_dev, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(p > 0.f, HGV_EINVAL, "bn_act_bwd2: two draws need p > 0");
+    HGV_REQUIRE(H <= HGV_BN_PAIR_MAX_H, HGV_EUNSUPPORTED, "bn_act_bwd2: H=%d exceeds %d (use two hgv_bn_act_bwd calls)", H, HGV_BN_PAIR_MAX_H);
+    HGV_REQUIRE(g && ldg >= H && h && ldh >= H && dy && lddy >= H && save_mean && save_rstd && ws && (!g2 || ldg2 >= H) &&
+                (!h2 || ldh2 >= H), HGV_EINVAL, "bn_act_bwd2: null/short buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd2: workspace too small or misaligned");
+    a.offset2 = offset2;
+    const int Hp = a.CH * 4;
+    HGV_REQUIRE(vec4_ok(y, ldy, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(h, ldh, Hp) && vec4_ok(h2, ldh2, Hp) &&
+                vec4_ok(dy, lddy, Hp), HGV_EUNSUPPORTED, "bn_act_bwd2: rows must be 16-byte aligned with padded leading dimensions");
+    float* partial = (float*)ws;
+    float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, h, ldh, h2, ldh2};
+    hipLaunchKernelGGL((k_ep_bwd_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 2);
+    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb), dim3(256), (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
+    HGV_CHECK_LAUNCH("bn_act_bwd2");
     return HGV_OK;
 }

@@ -662,6 +662,98 @@ class _BnAct(torch.autograd.Function):
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 12
 
 
+class _BnActPair(torch.autograd.Function):
+    """Two dropout draws of one pre-activation, (relu) -> dropout -> batch norm each, over one read of it: what two
+    :class:`_BnAct` calls on the same ``y`` compute (same statistics, same running-buffer updates in order, bit for bit),
+    with the two input gradients added inside the backward kernel.  Every output comes back as a pair of handles."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, seed, offset, offset2, ctr, eps, momentum, tracked):
+        n, h = y.shape
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
+        out, out2 = new_padded(n, h, y.device, zero_pad=False), new_padded(n, h, y.device, zero_pad=False)
+        stats = torch.empty(2, 2, h, dtype=torch.float32, device=y.device)          # [mean | rstd][draw][h]
+        _lib.call("hgv_bn_act_fwd2", y.data_ptr(), ld_of(y), n, h, int(relu), float(p), seed, offset, offset2, ctr,
+                  _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
+                  float(momentum), _lib.ptr(tracked), stats[0].data_ptr(), stats[1].data_ptr(), out.data_ptr(),
+                  out2.data_ptr(), ld_of(out), ws.data_ptr(), ws.numel(), _lib.stream())
+        ctx.cfg = (relu, p, seed, offset, offset2, ctr)
+        ctx.save_for_backward(y, gamma, stats, beta)
+        ctx.set_materialize_grads(False)
+        return out, out.view_as(out), out2, out2.view_as(out2)
+
+    @staticmethod
+    def backward(ctx, g, g2, h, h2):
+        y, gamma, stats, beta = ctx.saved_tensors
+        relu, p, seed, offset, offset2, ctr = ctx.cfg
+        if g is None:
+            g, g2 = g2, None
+        if h is None:
+            h, h2 = h2, None
+        if g is None and h is None:
+            return (None,) * 14
+        n, hh = y.shape
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, hh), y.device, "bn")
+        need = ctx.needs_input_grad
+        gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
+        direct = gbuf is not None and bbuf is not None
+        dgamma = gbuf if direct else torch.empty(hh, dtype=torch.float32, device=y.device)
+        dbeta = bbuf if direct else torch.empty(hh, dtype=torch.float32, device=y.device)
+        dy = new_padded(n, hh, y.device, zero_pad=False)
+        grads = [as_padded(rowmajor(t)) if t is not None else None for t in (g, g2, h, h2)]
+        if grads[0] is None or grads[2] is None:
+            # only one of the two draws reached the loss: the single-draw kernels on that draw
+            first = grads[0] is not None
+            a, a2 = (grads[0], grads[1]) if first else (grads[2], grads[3])
+            k = 0 if first else 1
+            _lib.call("hgv_bn_act_bwd", a.data_ptr(), ld_of(a), _lib.ptr(a2), ld_of(a2) if a2 is not None else 0, y.data_ptr(),
+                      ld_of(y), n, hh, int(relu), float(p), None, seed, offset if first else offset2, ctr, _lib.ptr(gamma),
+                      stats[0, k].data_ptr(), stats[1, k].data_ptr(), dy.data_ptr(), ld_of(dy), dgamma.data_ptr(),
+                      dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        else:
+            a, a2, b, b2 = grads
+            _lib.call("hgv_bn_act_bwd2", a.data_ptr(), ld_of(a), _lib.ptr(a2), ld_of(a2) if a2 is not None else 0,
+                      b.data_ptr(), ld_of(b), _lib.ptr(b2), ld_of(b2) if b2 is not None else 0, y.data_ptr(), ld_of(y), n, hh,
+                      int(relu), float(p), seed, offset, offset2, ctr, _lib.ptr(gamma), stats[0].data_ptr(),
+                      stats[1].data_ptr(), dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(),
+                      1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        if direct:
+            dgamma = dbeta = None
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 11
+
+
+_pair_epilogues = os.environ.get("HGVAE_PAIR_EPILOGUES", "1") != "0"      # 0: always two separate calls (A/B measurements)
+
+
+def bn_act_pair(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float):
+    """Training-mode ``bn_act(y, ..., fork=True)`` for two successive dropout draws of the same ``y`` (the two encode
+    passes of a train step over the shared first convolution): ``((out_a, out_a'), (out_b, out_b'))``, or None when
+    the fused kernels do not apply (explicit noise tapes, p = 0, unaligned rows, no gradient) and the caller makes
+    two ordinary calls."""
+    _lib.require_cuda(y)
+    if not (_pair_epilogues and p > 0.0 and torch.is_grad_enabled() and y.requires_grad and y.dim() == 2 and y.size(1) <= 512 and is_vec4(y)):
+        return None
+    noise = current_noise()
+    mask, seed, offset, ctr = noise.dropout(y.shape, y.device)
+    if mask is not None:
+        raise _lib.HgvError("bn_act_pair: explicit dropout masks are consumed one call at a time; check noise_is_counter_based() first")
+    _, _, offset2, _ = noise.dropout(y.shape, y.device)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    a, a2, b, b2 = _BnActPair.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, seed, offset, offset2,
+                                    ctr, bn.eps, momentum, bn.num_batches_tracked)
+    return (a, a2), (b, b2)
+
+
+def noise_is_counter_based() -> bool:
+    """True when the current noise source derives masks from (seed, offset) inside the kernels (no explicit tape)."""
+    from .noise import PhiloxNoise
+    return isinstance(current_noise(), PhiloxNoise)
+
+
 class _BnActEval(torch.autograd.Function):
     """Evaluation mode: relu? -> identity -> batch norm with the running statistics, an elementwise affine map.  Its
     backward pass is the rare case (fine-tuning with frozen statistics, input gradients of a trained model) and is

@@ -110,6 +110,9 @@ class SkipconVAE(_VAEBase):
         so the convolution is also differentiated once, on the summed gradient).  The sharing is
         scoped to this context (one loss evaluation, no parameter update inside) and whatever is
         still pending is dropped on exit; outside it every call computes the convolution.
+        In training the first pass already runs the second pass's dropout and batch norm of that
+        level (one read of the convolution output for both, running statistics updated twice), so
+        the context is for exactly the reference's pair of passes over one batch.
         """
         prev, self._conv1_memo = self._conv1_memo, []
         try:
@@ -117,18 +120,27 @@ class SkipconVAE(_VAEBase):
         finally:
             self._conv1_memo = prev
 
-    def _conv1(self, x, g):
-        conv = self.encoder1[0]
+    def _level1(self, x, g):
+        """First encoder level -> (x1, skip1).  Inside :meth:`share_first_conv` the first call also prepares the second
+        pass: in training with counter-based noise both dropout draws and both batch norms are computed over one read
+        of the convolution output (``Fn.bn_act_pair``) and the second pass only collects its pair; otherwise the
+        convolution output itself is kept and the second pass runs its own relu -> dropout -> batch norm on it."""
+        conv, drop, bn = self.encoder1[0], self.encoder1[1], self.encoder1[2]
         memo = self._conv1_memo
         if memo is None:
-            return conv(x, g)
+            return self._finish(conv(x, g), drop, bn, relu=True, fork=True)
         if memo and memo[0] is x and memo[1] is g and memo[2] == torch.is_grad_enabled():
-            y = memo[3]
+            kind, kept = memo[3]
             memo.clear()
-            return y
-        y, y_again = Fn.fork(conv(x, g))
-        memo[:] = [x, g, torch.is_grad_enabled(), y_again]
-        return y
+            return kept if kind == "levels" else self._finish(kept, drop, bn, relu=True, fork=True)
+        y = conv(x, g)
+        pair = Fn.bn_act_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
+        if pair is not None:
+            memo[:] = [x, g, torch.is_grad_enabled(), ("levels", pair[1])]
+            return pair[0]
+        y, y_again = Fn.fork(y)
+        memo[:] = [x, g, torch.is_grad_enabled(), ("preact", y_again)]
+        return self._finish(y, drop, bn, relu=True, fork=True)
 
     def _make_level2(self, h, p):
         return nn.Sequential(SAGEConv(h, h), nn.Dropout(p), nn.BatchNorm1d(h))
@@ -141,7 +153,7 @@ class SkipconVAE(_VAEBase):
         x = padded_input(x)
         # x1 / x2 feed the next level and, as skips, the decoder: the level's epilogue hands out two handles and its
         # backward pass adds the two incoming gradients inside the kernels
-        x1, skip1 = self._finish(self._conv1(x, g), self.encoder1[1], self.encoder1[2], relu=True, fork=True)
+        x1, skip1 = self._level1(x, g)
         x2, skip2 = self._level2(x1, g)
         x3 = self._sage_level(self.encoder3, x2, g)
         mean, log_std = split_head(self.encoder3[3](x3, g), self.out_channels)

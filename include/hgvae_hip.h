@@ -142,6 +142,25 @@ int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int64_t ldg2, c
                    const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* save_mean,
                    const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, int accumulate,
                    void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* Two dropout draws of ONE pre-activation over one read of it.  The reference encodes every batch twice per train
+ * step (gvae/gvae_skipcon.py:166-171: model(...), then model.encode(...) again); nothing stochastic precedes the first
+ * convolution, so both passes apply relu -> Dropout -> BatchNorm1d (:105-107) to the same matrix with different masks.
+ * hgv_bn_act_fwd2 = hgv_bn_act_fwd with Philox offset `offset` into out, then with `offset2` into out2 (running
+ * statistics updated in that order, num_batches_tracked += 2), save_mean / save_rstd = [2][H].  hgv_bn_act_bwd2: g / g2
+ * are the incoming gradients of out, h / h2 those of out2 (g2, h2 nullable); dy is the SUM of the two input gradients,
+ * dgamma / dbeta the sums over both draws.  Results equal those of the two separate calls bit for bit.  Philox noise with
+ * p > 0 and H <= 512 only; every matrix 16-byte aligned with a leading dimension that is a multiple of 4 (HGV_EUNSUPPORTED
+ * otherwise). */
+int hgv_bn_act_fwd2(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, uint64_t seed, uint64_t offset,
+                    uint64_t offset2, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
+                    float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                    float* save_mean, float* save_rstd, float* out, float* out2, int64_t ldo, void* ws, size_t ws_bytes,
+                    hgv_stream_t stream);
+int hgv_bn_act_bwd2(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* h, int64_t ldh,
+                    const float* h2, int64_t ldh2, const float* y, int64_t ldy, int64_t N, int H, int relu, float p,
+                    uint64_t seed, uint64_t offset, uint64_t offset2, const uint64_t* offset_dev, const float* gamma,
+                    const float* save_mean, const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta,
+                    int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 /* ---- reparameterisation / KL / MSE: gvae/gvae_skipcon.py:138-142, :153-156, :174 ----------
  * ml = [mean | log_std], [N, 2Z] with leading dimension ldm.

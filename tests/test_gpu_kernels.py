@@ -188,6 +188,49 @@ def test_bn_act_forward_backward(H, relu, p):
     close(out_e, ref_e, FWD_RTOL)
 
 
+@pytest.mark.parametrize("n,H,relu,p", [(1237, 138, True, 0.5), (4999, 256, True, 0.49), (70, 6, False, 0.3), (20011, 276, True, 0.5)])
+@pytest.mark.parametrize("consumers", ["both_twice", "second_once", "only_first"])
+def test_bn_act_pair_equals_two_calls_bit_for_bit(n, H, relu, p, consumers):
+    """Two dropout draws of one pre-activation in one pass: outputs, saved statistics, running buffers, the summed input
+    gradient and the affine gradients are those of two ordinary calls on the same matrix (same Philox offsets)."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import new_padded
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    gen = torch.Generator().manual_seed(n + H)
+    y0 = new_padded(n, H, dev())
+    y0.copy_((torch.randn(n, H, generator=gen) * 1.3 + 0.2).to(dev()))
+    gs = [torch.randn(n, H, generator=gen).to(dev()) for _ in range(4)]
+
+    def run(paired):
+        bn = torch.nn.BatchNorm1d(H).to(dev())
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(H, generator=torch.Generator().manual_seed(1)) + 0.5)
+            bn.bias.copy_(torch.randn(H, generator=torch.Generator().manual_seed(2)))
+        y = y0.detach().requires_grad_(True)
+        with use_noise(PhiloxNoise(77)):
+            if paired:
+                (a, a2), (b, b2) = Fn.bn_act_pair(y, bn, relu, p)
+            else:
+                ya, yb = Fn.fork(y)
+                a, a2 = Fn.bn_act(ya, bn, relu, p, True, fork=True)
+                b, b2 = Fn.bn_act(yb, bn, relu, p, True, fork=True)
+        if consumers == "both_twice":
+            loss = (a * gs[0]).sum() + (a2 * gs[1]).sum() + (b * gs[2]).sum() + (b2 * gs[3]).sum()
+        elif consumers == "second_once":
+            loss = (a * gs[0]).sum() + (a2 * gs[1]).sum() + (b * gs[2]).sum()
+        else:
+            loss = (a2 * gs[1]).sum()
+        loss.backward()
+        return (a.detach(), b.detach(), y.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone(),
+                int(bn.num_batches_tracked))
+
+    got, want = run(True), run(False)
+    assert not torch.equal(got[0], got[1])                      # two different draws
+    for g, w in zip(got[:-1], want[:-1]):
+        assert torch.equal(g, w)
+    assert got[-1] == want[-1] == 2
+
+
 def test_bn_act_large_mean_is_stable():
     """Columns with mean >> std: shifted sums must not lose the variance."""
     from hgvae_amd import functional as Fn

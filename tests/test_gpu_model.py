@@ -452,7 +452,7 @@ def test_training_with_torch_adam_tracks_flat_adam(fused):
             loss.backward()
             bucket.all_reduce_mean()
             opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         return losses
 
     a, b = run("flat"), run("torch")
@@ -487,3 +487,40 @@ def test_direct_weight_grads_match_autograd_accumulation():
     a, b = flats
     assert float(a.abs().max()) > 0
     assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+@pytest.mark.parametrize("variant", ["skipcon", "attention"])
+def test_paired_first_level_equals_two_separate_epilogues(variant, monkeypatch):
+    """Inside a train step the first level's relu -> dropout -> batch norm of both encode passes runs as one paired
+    operator over the shared convolution output.  With the operator replaced by two ordinary calls that draw the same
+    Philox offsets, the loss, every gradient and every BatchNorm buffer must come out bit for bit the same."""
+    import hgvae_amd
+    from hgvae_amd import functional as Fn
+    from hgvae_amd import synthetic
+    from hgvae_amd.vae import SkipconAttentionVAE, SkipconVAE, train_step_loss
+    dev = torch.device("cuda:0")
+    batch = synthetic.path_graph_batch([138] * 5 + [61], 60, seed=4, device=dev)
+
+    def two_calls(y, bn, relu, p):
+        ya, yb = Fn.fork(y)
+        return Fn.bn_act(ya, bn, relu, p, True, fork=True), Fn.bn_act(yb, bn, relu, p, True, fork=True)
+
+    results = []
+    for paired in (True, False):
+        if not paired:
+            monkeypatch.setattr(Fn, "bn_act_pair", two_calls)
+        torch.manual_seed(0)
+        hgvae_amd.manual_seed(9)
+        model = (SkipconVAE(60, 138, 28) if variant == "skipcon" else SkipconAttentionVAE(60, 64, 28)).to(dev).train()
+        losses = []
+        for _ in range(2):
+            model.zero_grad()
+            loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+            loss.backward()
+            losses.append(loss.detach().clone())
+        results.append((losses, [p.grad.clone() for p in model.parameters()], [b.clone() for b in model.buffers()]))
+    (la, ga, ba), (lb, gb, bb) = results
+    assert all(torch.equal(x, y) for x, y in zip(la, lb))
+    assert all(torch.equal(x, y) for x, y in zip(ga, gb))
+    assert all(torch.equal(x, y) for x, y in zip(ba, bb))
+    assert int(ba[2]) == 4          # encoder1's BatchNorm saw two batches per step
