@@ -25,6 +25,9 @@ SIGNATURES = {
     "hgv_sort_pairs_u32": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "hgv_agg_fwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
     "hgv_agg_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "hgv_csr_long_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _vp]),
+    "hgv_agg_fwd_long": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp,
+                                   _i32, _i32, _vp]),
     "hgv_bn_act_ws": (_sz, [_i64, _i32]),
     "hgv_bn_act_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _f32, _vp, _vp,
                                  _f32, _vp, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),

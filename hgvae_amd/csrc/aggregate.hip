@@ -64,6 +64,7 @@ struct AggArgs {
     int64_t ldadd;
     float* out;
     int64_t ldo;
+    int long_threshold;    // > 0: rows with more entries than this are left to k_aggregate_long
 };
 
 // NB neighbour rows (x CPL chunks) of one segment position in flight per lane; adds stay in segment order
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
     const int64_t row = wave * rows_per_wave + sub;
     if (row >= a.n_rows) return;
     const int start = a.rowptr[row], end = a.rowptr[row + 1];
+    if (a.long_threshold > 0 && end - start > a.long_threshold) return;     // the whole group leaves: a long row has its own kernel
 
     // Every lane of the group walks the segment (it is the shuffle source for its slot of
     // column indices); lanes past the last chunk shadow the last chunk and store nothing.
@@ -151,13 +153,96 @@ __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
     }
 }
 
+// Rows far longer than the average ("hubs").  A lane group walks its row alone, a few neighbour rows at a time, so one
+// row of 2 000 entries takes longer than the rest of a 100 k-row launch together.  Such rows are listed once per CSR
+// (k_long_rows) and summed by a whole 1024-thread workgroup each: wave w of 16 takes the w-th sixteenth of the segment
+// (in order), a lane owns one feature chunk per pass, and the sixteen partial sums are added in wave order through LDS
+// - no atomics, the same result on every run; for these rows the order of the additions is blocked, not sequential.
+constexpr int LONG_WAVES = 16;
+
+__global__ __launch_bounds__(256) void k_long_rows(const int32_t* __restrict__ rowptr, int64_t n_rows, int threshold,
+                                                   int32_t* __restrict__ rows, int cap, int32_t* __restrict__ count) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+        if (rowptr[i + 1] - rowptr[i] > threshold) {
+            const int pos = atomicAdd(count, 1);          // list order is irrelevant: every listed row is summed on its own
+            if (pos < cap) rows[pos] = (int32_t)i;
+        }
+    }
+}
+
+template <int VEC, bool WEIGHTED>
+__global__ __launch_bounds__(64 * LONG_WAVES) void k_aggregate_long(const AggArgs a, const int32_t* __restrict__ rows,
+                                                                    const int32_t* __restrict__ count, int cap) {
+    using V = typename VecT<VEC>::T;
+    __shared__ float4 sh4[LONG_WAVES * 64];
+    V* sh = reinterpret_cast<V*>(sh4);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n_long = min(count[0], cap);
+    for (int idx = blockIdx.x; idx < n_long; idx += gridDim.x) {
+        const int64_t row = rows[idx];
+        const int start = a.rowptr[row], end = a.rowptr[row + 1];
+        const int len = end - start;
+        const int s0 = start + (int)((int64_t)len * w / LONG_WAVES), s1 = start + (int)((int64_t)len * (w + 1) / LONG_WAVES);
+        for (int c0 = 0; c0 < a.nchunks; c0 += 64) {
+            const int c = c0 + lane;
+            const bool owns = c < a.nchunks;
+            const int coff = (owns ? c : a.nchunks - 1) * VEC;
+            V acc;
+            vzero<VEC>(acc);
+            for (int base = s0; base < s1; base += 64) {
+                const int k = base + lane;
+                int my_col = 0;
+                float my_w = 1.f;
+                if (k < s1) {
+                    my_col = a.col[k];
+                    if (WEIGHTED) {
+                        if (a.edge_w) my_w = a.edge_w[k];
+                        if (a.nbr_w) my_w *= a.nbr_w[my_col];
+                    }
+                }
+                const int cnt = min(64, s1 - base);
+                int j = 0;
+                for (; j + 4 <= cnt; j += 4) {
+                    V v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(a.x + (int64_t)__shfl(my_col, j + u, 64) * a.ldx + coff);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (WEIGHTED) vmad(acc, __shfl(my_w, j + u, 64), v[u]);
+                        else vadd(acc, v[u]);
+                    }
+                }
+                for (; j < cnt; ++j) {
+                    const V v = *reinterpret_cast<const V*>(a.x + (int64_t)__shfl(my_col, j, 64) * a.ldx + coff);
+                    if (WEIGHTED) vmad(acc, __shfl(my_w, j, 64), v);
+                    else vadd(acc, v);
+                }
+            }
+            sh[w * 64 + lane] = acc;
+            __syncthreads();
+            if (w == 0) {
+                V tot = sh[lane];
+                for (int q = 1; q < LONG_WAVES; ++q) vadd(tot, sh[q * 64 + lane]);
+                if (a.row_mode == 1) vdiv(tot, (float)(len > 1 ? len : 1));
+                else if (a.row_mode == 2) vscale(tot, a.row_scale[row]);
+                if (owns) {
+                    if (a.add) vadd(tot, *reinterpret_cast<const V*>(a.add + row * a.ldadd + coff));
+                    *reinterpret_cast<V*>(a.out + row * a.ldo + coff) = tot;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 bool vec_ok(int vec, int F, const float* p, int64_t ld) {
     if (p == nullptr) return true;
     const int64_t need = hgv_cdiv(F, vec) * vec;
     return hgv_aligned(p, 4 * vec) && (ld % vec == 0) && ld >= need;
 }
 
-int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
+int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st, const int32_t* long_rows = nullptr,
+                     const int32_t* long_count = nullptr, int long_cap = 0) {
     int vec = 4;
     while (vec > 1 && !(vec_ok(vec, F, a.x, a.ldx) && vec_ok(vec, F, a.out, a.ldo) && vec_ok(vec, F, a.add, a.ldadd)))
         vec >>= 1;
@@ -204,6 +289,14 @@ int launch_aggregate(AggArgs a, int F, bool weighted, hipStream_t st) {
     if (vec == 4) { HGV_AGG_LAUNCH(4) } else if (vec == 2) { HGV_AGG_LAUNCH(2) } else { HGV_AGG_LAUNCH(1) }
 #undef HGV_AGG_LAUNCH
 #undef HGV_AGG_CPL
+    if (long_rows != nullptr && long_cap > 0) {
+        dim3 lg((unsigned)(long_cap < 128 ? long_cap : 128)), lb(64 * LONG_WAVES);
+#define HGV_AGG_LONG(V)                                                                                              \
+        if (weighted) hipLaunchKernelGGL((k_aggregate_long<V, true>), lg, lb, 0, st, a, long_rows, long_count, long_cap);   \
+        else hipLaunchKernelGGL((k_aggregate_long<V, false>), lg, lb, 0, st, a, long_rows, long_count, long_cap);
+        if (vec == 4) { HGV_AGG_LONG(4) } else if (vec == 2) { HGV_AGG_LONG(2) } else { HGV_AGG_LONG(1) }
+#undef HGV_AGG_LONG
+    }
     HGV_CHECK_LAUNCH("aggregate");
     return HGV_OK;
 }
@@ -221,8 +314,40 @@ extern "C" int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_
     HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd: null buffer");
     HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd: leading dimension < F");
     HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd: bad row_mode");
-    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo};
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, 0};
     return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream);
+}
+
+// Rows of a CSR with more than `threshold` entries, in no particular order: rows[0 .. min(count, cap)) and their number in
+// count[0], which must be zero on entry.  cap >= E / threshold + 1 always suffices.
+extern "C" int hgv_csr_long_rows(const int32_t* rowptr, int64_t n_rows, int threshold, int32_t* rows, int cap,
+                                 int32_t* count, hipStream_t stream) {
+    HGV_REQUIRE(n_rows >= 0 && threshold > 0 && cap > 0 && rows && count, HGV_EINVAL, "csr_long_rows: bad argument");
+    if (n_rows == 0) return HGV_OK;
+    HGV_REQUIRE(rowptr, HGV_EINVAL, "csr_long_rows: null rowptr");
+    const int64_t blocks = hgv_cdiv(n_rows, 256);
+    hipLaunchKernelGGL(k_long_rows, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, rowptr, n_rows, threshold, rows, cap, count);
+    HGV_CHECK_LAUNCH("csr_long_rows");
+    return HGV_OK;
+}
+
+// hgv_agg_fwd for graphs with hubs: rows longer than `threshold` are skipped by the row-per-lane-group kernel; with
+// run_long_pass != 0 a second launch sums the rows listed by hgv_csr_long_rows (same threshold) with one workgroup per
+// row.  run_long_pass = 0 is for callers that know the list is empty.  Every row is written by exactly one of the two.
+extern "C" int hgv_agg_fwd_long(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx,
+                                int F, int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w,
+                                const float* add, int64_t ldadd, float* out, int64_t ldo, int threshold,
+                                const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
+                                hipStream_t stream) {
+    HGV_REQUIRE(n_rows >= 0 && F >= 0, HGV_EINVAL, "agg_fwd_long: negative size");
+    if (n_rows == 0 || F == 0) return HGV_OK;
+    HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd_long: null buffer");
+    HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd_long: leading dimension < F");
+    HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd_long: bad row_mode");
+    HGV_REQUIRE(threshold > 0 && long_rows && long_count && long_cap > 0, HGV_EINVAL, "agg_fwd_long: bad long-row list");
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold};
+    return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream, run_long_pass ? long_rows : nullptr, long_count,
+                            long_cap);
 }
 
 // Backward of the mean/sum aggregation with respect to x: run over the transposed CSR

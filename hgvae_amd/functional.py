@@ -70,9 +70,13 @@ def _agg_launch(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out)
 
 
 def _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, out):
-    _lib.call("hgv_agg_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), n_rows, x.data_ptr(), ld_of(x), F, row_mode,
+    # rows far longer than the average (hubs) go to a workgroup-per-row pass, which is launched unless the device
+    # has already reported that this CSR has none
+    lr = csr.long_rows(n_rows)
+    _lib.call("hgv_agg_fwd_long", csr.rowptr.data_ptr(), csr.col.data_ptr(), n_rows, x.data_ptr(), ld_of(x), F, row_mode,
               _lib.ptr(row_scale), _lib.ptr(edge_w), _lib.ptr(nbr_w), _lib.ptr(add),
-              ld_of(add) if add is not None else 0, out.data_ptr(), ld_of(out), _lib.stream())
+              ld_of(add) if add is not None else 0, out.data_ptr(), ld_of(out), lr.threshold, lr.rows.data_ptr(),
+              lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0, _lib.stream())
 
 
 class _Aggregate(torch.autograd.Function):

@@ -61,11 +61,45 @@ def as_padded(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _LongRows:
+    """Rows of a CSR that are far longer than the average (hubs), listed on the device once per CSR.  Whether there
+    are any reaches the host through an asynchronous copy; until it has arrived the answer is "maybe"."""
+    __slots__ = ("threshold", "rows", "count", "cap", "_host", "_event", "_known")
+
+    def __init__(self, rowptr: torch.Tensor, n_rows: int, n_entries: int):
+        dev = rowptr.device
+        self.threshold = max(64, 4 * -(-n_entries // max(n_rows, 1)))
+        self.cap = n_entries // self.threshold + 1
+        self.rows = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("hgv_csr_long_rows", rowptr.data_ptr(), n_rows, self.threshold, self.rows.data_ptr(), self.cap,
+                  self.count.data_ptr(), _lib.stream())
+        self._known: Optional[int] = None
+        self._host = self._event = None
+        if not torch.cuda.is_current_stream_capturing():      # a capture must not hold host copies or foreign events
+            self._host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self._host.copy_(self.count, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+
+    def maybe_any(self) -> bool:
+        """False only once the device has reported an empty list (never blocks)."""
+        if self._known is None and self._event is not None and self._event.query():
+            self._known = int(self._host[0])
+        return self._known is None or self._known > 0
+
+
 class _Csr:
-    __slots__ = ("rowptr", "col", "perm")
+    __slots__ = ("rowptr", "col", "perm", "_long")
 
     def __init__(self, rowptr, col, perm):
         self.rowptr, self.col, self.perm = rowptr, col, perm
+        self._long = None
+
+    def long_rows(self, n_rows: int) -> _LongRows:
+        if self._long is None:
+            self._long = _LongRows(self.rowptr, n_rows, int(self.col.numel()))
+        return self._long
 
 
 def _build_csr(edge_index: torch.Tensor, n: int, by_src: bool, status: torch.Tensor) -> _Csr:

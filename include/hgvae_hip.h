@@ -108,6 +108,20 @@ int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const
 int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_t n_rows, const float* g, int64_t ldg, int F,
                 const float* inv_deg, const float* edge_w_t, const float* add, int64_t ldadd, float* gx,
                 int64_t ldgx, hgv_stream_t stream);
+/* The same aggregation (same call sites as hgv_agg_fwd) for graphs with hub nodes.  hgv_agg_fwd gives every row to one
+ * lane group, which walks it alone: a row of thousands of entries (the out-edges of a hub in the transposed CSR of
+ * loss.backward(), gvae/gvae_skipcon.py:183) then outlasts the rest of the launch.  hgv_csr_long_rows lists, once per CSR,
+ * the rows with more than `threshold` entries (rows[0 .. min(count, cap)), count[0] zero on entry, order unspecified,
+ * cap >= E / threshold + 1 suffices); hgv_agg_fwd_long leaves those rows out of the row-per-group kernel and, with
+ * run_long_pass != 0, sums each of them with a 1024-thread workgroup (16 in-order sixteenths of the segment, partial sums
+ * added in fixed order: deterministic, but blocked rather than sequential summation for these rows).  run_long_pass = 0
+ * is for callers that know the list is empty. */
+int hgv_csr_long_rows(const int32_t* rowptr, int64_t n_rows, int threshold, int32_t* rows, int cap, int32_t* count,
+                      hgv_stream_t stream);
+int hgv_agg_fwd_long(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx, int F,
+                     int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w, const float* add,
+                     int64_t ldadd, float* out, int64_t ldo, int threshold, const int32_t* long_rows,
+                     const int32_t* long_count, int long_cap, int run_long_pass, hgv_stream_t stream);
 
 /* ---- fused (ReLU) -> Dropout -> BatchNorm1d over nodes: gvae/gvae_skipcon.py:105-107,
  *      110-112,115-117,124,130,136 ----------------------------------------------------------

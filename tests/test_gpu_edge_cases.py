@@ -98,3 +98,61 @@ def test_sag_pooling_single_node_and_edgeless_graphs():
     assert torch.equal(got[4].cpu(), want[4])                    # perm
     assert torch.allclose(got[0].cpu(), want[0], rtol=1e-5, atol=1e-6)
     assert torch.equal(got[1].cpu(), want[1]) and torch.equal(got[3].cpu(), want[3])
+
+
+@pytest.mark.parametrize("F", [6, 128, 138, 276])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_aggregation_with_hub_rows(F, weighted):
+    """Rows far longer than the average (two hubs of ~2 000 and ~700 entries among rows of ~8) take the workgroup-per-row
+    pass; everything else the row-per-lane-group kernel.  Against float64 index_add_, forward, mean and transposed."""
+    import torch
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(F)
+    n, e = 3000, 24000
+    src = torch.randint(0, n, (e,), generator=gen)
+    dst = torch.randint(0, n, (e,), generator=gen)
+    dst[:2000] = 17                                   # hub in the by-target CSR
+    src[2000:2700] = 2999                             # hub in the by-source CSR (last row)
+    ei = torch.stack([src, dst]).to(dev)
+    g = Graph(ei, n)
+    assert g.by_dst.long_rows(n).threshold == 64
+    x = torch.randn(n, F, generator=gen).to(dev).requires_grad_(True)
+    if weighted:
+        w = torch.rand(e, generator=gen).to(dev)
+        out = Fn._WeightedAggregate.apply(x, g, w[g.by_dst.perm.long()])
+        want = torch.zeros(n, F, dtype=torch.float64, device=dev).index_add_(0, ei[1], x.detach().double()[ei[0]] * w.double()[:, None])
+    else:
+        out = Fn.aggregate(x, g, mean=True)
+        deg = torch.bincount(ei[1], minlength=n).clamp(min=1).double()[:, None]
+        want = torch.zeros(n, F, dtype=torch.float64, device=dev).index_add_(0, ei[1], x.detach().double()[ei[0]]) / deg
+    torch.cuda.synchronize()
+    assert g.by_dst.long_rows(n).maybe_any() and int(g.by_dst.long_rows(n).count) == 1
+    scale = float(want.abs().max())
+    assert float((out.detach().double() - want).abs().max()) <= 2e-6 * scale
+    gout = torch.randn(n, F, generator=gen).to(dev)
+    out.backward(gout)
+    if weighted:
+        want_g = torch.zeros(n, F, dtype=torch.float64, device=dev).index_add_(0, ei[0], gout.double()[ei[1]] * w.double()[:, None])
+    else:
+        want_g = torch.zeros(n, F, dtype=torch.float64, device=dev).index_add_(0, ei[0], (gout.double() / deg)[ei[1]])
+    assert float((x.grad.double() - want_g).abs().max()) <= 2e-6 * float(want_g.abs().max())
+    # a second run gives the same bits (the partial sums of a hub row are combined in a fixed order)
+    again = Fn._WeightedAggregate.apply(x.detach(), g, w[g.by_dst.perm.long()]) if weighted else Fn.aggregate(x.detach(), g, mean=True)
+    assert torch.equal(again, out.detach())
+
+
+def test_graph_without_hubs_learns_that_the_long_pass_is_not_needed():
+    import torch
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import Graph
+    dev = torch.device("cuda:0")
+    n = 5000
+    a = torch.arange(n - 1, device=dev)
+    g = Graph(torch.stack([a, a + 1]), n)
+    x = torch.randn(n, 16, device=dev)
+    first = Fn.aggregate(x, g, mean=True)
+    torch.cuda.synchronize()
+    assert not g.by_dst.long_rows(n).maybe_any()
+    assert torch.equal(Fn.aggregate(x, g, mean=True), first)

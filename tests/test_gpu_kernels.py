@@ -106,7 +106,16 @@ def test_aggregate_forward_bit_exact(F, mean):
     g = Graph(ei.to(dev()), n)
     out = Fn.aggregate(x.to(dev()), g, mean=mean)
     assert out.shape == ref.shape
-    assert torch.equal(out.cpu(), ref), (out.cpu() - ref).abs().max()
+    # rows up to the long-row threshold are summed in edge order: the bits of a sequential scatter_add_.  The hub (row 3,
+    # 2 250 entries) is summed in sixteen in-order blocks whose partial sums are then added: same value to rounding.
+    hub = 3
+    assert int(g.in_degree[hub]) > g.by_dst.long_rows(n).threshold
+    rest = torch.arange(n) != hub
+    assert torch.equal(out.cpu()[rest], ref[rest]), (out.cpu() - ref).abs().max()
+    exact = (O.scatter_mean if mean else O.scatter_sum)(x.double().index_select(0, ei[0]), ei[1], n)[hub]
+    err_blocked, err_sequential = (out.cpu()[hub].double() - exact).abs().max(), (ref[hub].double() - exact).abs().max()
+    assert float(err_blocked) <= max(2.0 * float(err_sequential), 1e-6 * float(exact.abs().max()))
+    assert torch.equal(Fn.aggregate(x.to(dev()), g, mean=mean), out)
 
 
 def test_aggregate_known_answer_path():
