@@ -202,12 +202,12 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_aggregate_long(const AggArg
                 }
                 const int cnt = min(64, s1 - base);
                 int j = 0;
-                for (; j + 4 <= cnt; j += 4) {
-                    V v[4];
+                for (; j + 8 <= cnt; j += 8) {          // eight neighbour rows in flight per wave: the row is all this workgroup has
+                    V v[8];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(a.x + (int64_t)__shfl(my_col, j + u, 64) * a.ldx + coff);
+                    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const V*>(a.x + (int64_t)__shfl(my_col, j + u, 64) * a.ldx + coff);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 8; ++u) {
                         if (WEIGHTED) vmad(acc, __shfl(my_w, j + u, 64), v[u]);
                         else vadd(acc, v[u]);
                     }
