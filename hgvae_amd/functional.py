@@ -21,7 +21,7 @@ _ws_cache: "dict[tuple, torch.Tensor]" = {}
 
 def _workspace(nbytes: int, device, tag: str) -> torch.Tensor:
     """Per-(device, stream, tag) scratch buffer, grown on demand and reused across calls."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device.index, _lib.stream(), tag)        # raw handle of the current stream: no Stream object per call
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 4096), dtype=torch.uint8, device=device)
@@ -186,6 +186,30 @@ def set_projection(kind: str) -> None:
     _projection = kind
 
 
+_array_types: dict = {}
+_split_sizes: dict = {}
+
+
+def _split_image_floats(n: int, k1: int, k2: int) -> int:
+    """Size (in floats) of the split-bf16 image of an n x (k1 + k2) weight, 0 when the NT kernel does not take the shape."""
+    key = (n, k1, k2)
+    v = _split_sizes.get(key)
+    if v is None:
+        lib = _lib.load()
+        v = _split_sizes[key] = lib.hgv_pack16_bytes(n, k1, k2) // 4 if lib.hgv_gemm_nt16_supported(n, k1, k2) else 0
+    return v
+
+
+
+def _ctypes_arrays(n: int):
+    """(void*[n], int64[n], int[n]) ctypes array types; building such a type costs microseconds, so they are made once."""
+    t = _array_types.get(n)
+    if t is None:
+        import ctypes as C
+        t = _array_types[n] = (C.c_void_p * n, C.c_int64 * n, C.c_int * n)
+    return t
+
+
 class _Image:
     """Packed weight operand of one NT product: a split-bf16 image of [Wa | Wb] or fp32 images of Wa, Wb."""
     __slots__ = ("kind", "a", "b")
@@ -209,18 +233,19 @@ def _images(*specs) -> list:
         wa, wb, t = sp
         n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
         k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
-        if _projection == "bf16x6" and lib.hgv_gemm_nt16_supported(n, k1, k2):
+        if _projection == "bf16x6" and _split_image_floats(n, k1, k2) > 0:
             split.append((i, wa, wb, t, n, k1, k2))
         else:
             plain.append((i, wa, wb, t))
     for j0 in range(0, len(split), 4):
         jobs = split[j0:j0 + 4]
         nj = len(jobs)
-        sizes = [lib.hgv_pack16_bytes(n, k1, k2) // 4 for (_, _, _, _, n, k1, k2) in jobs]
+        sizes = [_split_image_floats(n, k1, k2) for (_, _, _, _, n, k1, k2) in jobs]
         buf = torch.empty(sum(sizes), dtype=torch.float32, device=jobs[0][1].device)
-        W1, W2, Op = (C.c_void_p * nj)(), (C.c_void_p * nj)(), (C.c_void_p * nj)()
-        sn1, sk1, sn2, sk2 = (C.c_int64 * nj)(), (C.c_int64 * nj)(), (C.c_int64 * nj)(), (C.c_int64 * nj)()
-        K1, K2, N = (C.c_int * nj)(), (C.c_int * nj)(), (C.c_int * nj)()
+        vp_t, i64_t, i32_t = _ctypes_arrays(nj)
+        W1, W2, Op = vp_t(), vp_t(), vp_t()
+        sn1, sk1, sn2, sk2 = i64_t(), i64_t(), i64_t(), i64_t()
+        K1, K2, N = i32_t(), i32_t(), i32_t()
         off = 0
         for q, ((i, wa, wb, t, n, k1, k2), sz) in enumerate(zip(jobs, sizes)):
             piece = buf[off:off + sz]
