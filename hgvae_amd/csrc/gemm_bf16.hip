@@ -80,14 +80,14 @@ struct Pack16Args {
     __bf16* out;
 };
 
-constexpr int PACK16_MAX_JOBS = 4;
+constexpr int PACK16_MAX_JOBS = 24;      // 24 x ~100 bytes of kernel arguments (limit 4 KB)
 struct Pack16Jobs {
     Pack16Args job[PACK16_MAX_JOBS];
     int first_block[PACK16_MAX_JOBS + 1];    // job q owns blocks [first_block[q], first_block[q+1])
     int njobs;
 };
 
-// one thread per (part, chunk, row, k) element of an image; writes the three pieces.  Up to four images per launch.
+// one thread per (part, chunk, row, k) element of an image; writes the three pieces.  Up to PACK16_MAX_JOBS images per launch.
 __global__ __launch_bounds__(256) void k_pack16(const Pack16Jobs jobs) {
     int q = 0;
 #pragma unroll
@@ -959,7 +959,7 @@ extern "C" int hgv_pack16_weights(const float* W1, int64_t sn1, int64_t sk1, int
     return launch_pack16(jobs, stream);
 }
 
-// Up to four images in one launch: job q packs [W1[q] | W2[q]] (W2[q] may be null, then K2[q] = 0) into out[q].
+// Up to 24 images in one launch: job q packs [W1[q] | W2[q]] (W2[q] may be null, then K2[q] = 0) into out[q].
 extern "C" int hgv_pack16_weights_multi(int njobs, const float* const* W1, const int64_t* sn1, const int64_t* sk1, const int* K1,
                                         const float* const* W2, const int64_t* sn2, const int64_t* sk2, const int* K2,
                                         const int* N, void* const* out, hipStream_t stream) {

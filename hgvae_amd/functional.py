@@ -218,39 +218,26 @@ class _Image:
         self.kind, self.a, self.b = kind, a, b
 
 
-def _images(*specs) -> list:
-    """Weight images for ``x_a @ op(wa)^T (+ x_b @ op(wb)^T)``: ``specs`` are ``(wa, wb, transposed)``
-    triples (None entries are skipped and returned as None) with op(w) = w or, with ``transposed``,
-    w^T (the grad-input product).  All images an operator needs are built by one launch per kind,
-    at every use (see :func:`_pack`)."""
-    import ctypes as C
-    lib = _lib.load()
-    out = [None] * len(specs)
-    split, plain = [], []
-    for i, sp in enumerate(specs):
-        if sp is None:
-            continue
-        wa, wb, t = sp
-        n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
-        k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
-        if _projection == "bf16x6" and _split_image_floats(n, k1, k2) > 0:
-            split.append((i, wa, wb, t, n, k1, k2))
-        else:
-            plain.append((i, wa, wb, t))
-    for j0 in range(0, len(split), 4):
-        jobs = split[j0:j0 + 4]
-        nj = len(jobs)
-        sizes = [_split_image_floats(n, k1, k2) for (_, _, _, _, n, k1, k2) in jobs]
-        buf = torch.empty(sum(sizes), dtype=torch.float32, device=jobs[0][1].device)
+PACK_MAX_JOBS = 24           # images per hgv_pack16_weights_multi launch
+
+
+def _pack_split(jobs) -> list:
+    """Split-bf16 images of ``jobs`` = [(wa, wb, transposed, n, k1, k2), ...], one launch per PACK_MAX_JOBS of them."""
+    out = []
+    for j0 in range(0, len(jobs), PACK_MAX_JOBS):
+        part = jobs[j0:j0 + PACK_MAX_JOBS]
+        nj = len(part)
+        sizes = [_split_image_floats(n, k1, k2) for (_, _, _, n, k1, k2) in part]
+        buf = torch.empty(sum(sizes), dtype=torch.float32, device=part[0][0].device)
         vp_t, i64_t, i32_t = _ctypes_arrays(nj)
         W1, W2, Op = vp_t(), vp_t(), vp_t()
         sn1, sk1, sn2, sk2 = i64_t(), i64_t(), i64_t(), i64_t()
         K1, K2, N = i32_t(), i32_t(), i32_t()
         off = 0
-        for q, ((i, wa, wb, t, n, k1, k2), sz) in enumerate(zip(jobs, sizes)):
+        for q, ((wa, wb, t, n, k1, k2), sz) in enumerate(zip(part, sizes)):
             piece = buf[off:off + sz]
             off += sz
-            out[i] = _Image("bf16x6", piece)
+            out.append(_Image("bf16x6", piece))
             W1[q], Op[q] = wa.data_ptr(), piece.data_ptr()
             sn1[q], sk1[q] = (wa.stride(1), wa.stride(0)) if t else (wa.stride(0), wa.stride(1))
             if wb is not None:
@@ -258,6 +245,122 @@ def _images(*specs) -> list:
                 sn2[q], sk2[q] = (wb.stride(1), wb.stride(0)) if t else (wb.stride(0), wb.stride(1))
             K1[q], K2[q], N[q] = k1, k2, n
         _lib.call("hgv_pack16_weights_multi", nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
+    return out
+
+
+class _ImageScope:
+    """Images packed up front for one loss evaluation, and the requests seen during it (next evaluation's plan)."""
+    __slots__ = ("images", "requests")
+
+    def __init__(self):
+        self.images, self.requests = {}, {}
+
+
+_image_scope: Optional[_ImageScope] = None
+
+
+def _plannable(w) -> bool:
+    """A weight the plan can find again: a leaf parameter or a view of one (e.g. a column block of a Linear weight)."""
+    if w is None:
+        return True
+    base = w._base if w._base is not None else w
+    return isinstance(base, torch.nn.Parameter) and base.is_leaf
+
+
+def _wkey(w):
+    return None if w is None else (w.data_ptr(), tuple(w.shape), w.stride())
+
+
+def _wref(w):
+    """(weak reference to the owning parameter, geometry of the view) - enough to find the same memory next time."""
+    import weakref
+    base = w._base if w._base is not None else w
+    return weakref.ref(base), tuple(w.shape), w.stride(), w.storage_offset()
+
+
+def _wresolve(entry):
+    ref, shape, stride, offset = entry
+    base = ref()
+    if base is None or not base.is_cuda:
+        return None
+    if tuple(base.shape) == shape and base.stride() == stride and base.storage_offset() == offset:
+        return base
+    need = offset + sum((n - 1) * st for n, st in zip(shape, stride)) + 1 if all(shape) else 0
+    if need > base.untyped_storage().nbytes() // base.element_size():
+        return None
+    return base.detach().as_strided(shape, stride, offset)
+
+
+@contextlib.contextmanager
+def weight_images(owner):
+    """One loss evaluation of ``owner`` (a module) during which no parameter changes.
+
+    Every projection operator packs the split-bf16 images of its weights when it runs - one small launch per
+    operator, a dozen per train step.  Inside this context the images that the previous evaluation of the same
+    owner (in the same grad mode) asked for are packed by ONE launch at entry, from the weights as they are now, and
+    the operators pick them up; whatever is asked for beyond that is packed on the spot as usual and joins the plan
+    of the next evaluation.  Nothing outlives the context except the plan (weak references and shapes), so an image
+    can never be older than the evaluation that uses it.  Only leaf parameters are planned."""
+    global _image_scope
+    if _projection != "bf16x6":
+        yield
+        return
+    attr = "_hgv_image_plan_grad" if torch.is_grad_enabled() else "_hgv_image_plan_nograd"
+    scope = _ImageScope()
+    plan = getattr(owner, attr, None) or []
+    jobs, keys = [], []
+    for (ea, eb, t) in plan:
+        wa, wb = _wresolve(ea), (_wresolve(eb) if eb is not None else None)
+        if wa is None or (eb is not None and wb is None):
+            continue
+        n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
+        k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
+        if _split_image_floats(n, k1, k2) > 0:
+            jobs.append((wa, wb, t, n, k1, k2))
+            keys.append((_wkey(wa), _wkey(wb), t))
+    if jobs:
+        for key, img in zip(keys, _pack_split(jobs)):
+            scope.images[key] = img
+    prev, _image_scope = _image_scope, scope
+    try:
+        yield
+    finally:
+        _image_scope = prev
+        object.__setattr__(owner, attr, list(scope.requests.values()))
+
+
+def _images(*specs) -> list:
+    """Weight images for ``x_a @ op(wa)^T (+ x_b @ op(wb)^T)``: ``specs`` are ``(wa, wb, transposed)``
+    triples (None entries are skipped and returned as None) with op(w) = w or, with ``transposed``,
+    w^T (the grad-input product).  All images an operator needs are built by one launch per kind,
+    at every use (see :func:`_pack`), unless a :func:`weight_images` context has packed them already."""
+    out = [None] * len(specs)
+    split, plain = [], []
+    scope = _image_scope
+    for i, sp in enumerate(specs):
+        if sp is None:
+            continue
+        wa, wb, t = sp
+        n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
+        k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
+        if _projection == "bf16x6" and _split_image_floats(n, k1, k2) > 0:
+            if scope is not None and _plannable(wa) and _plannable(wb):
+                key = (_wkey(wa), _wkey(wb), t)
+                if key not in scope.requests:
+                    scope.requests[key] = (_wref(wa), _wref(wb) if wb is not None else None, t)
+                hit = scope.images.get(key)
+                if hit is not None:
+                    out[i] = hit
+                    continue
+            split.append((i, wa, wb, t, n, k1, k2))
+        else:
+            plain.append((i, wa, wb, t))
+    if split:
+        imgs = _pack_split([(wa, wb, t, n, k1, k2) for (_, wa, wb, t, n, k1, k2) in split])
+        for (i, wa, wb, t, _n, _k1, _k2), img in zip(split, imgs):
+            out[i] = img
+            if scope is not None and _plannable(wa) and _plannable(wb):      # the second encode pass reuses it
+                scope.images[(_wkey(wa), _wkey(wb), t)] = img
     # fp32 images: two weights per image at most, four weights per launch
     flat = [(i, which, w, t) for (i, wa, wb, t) in plain for (which, w) in (("a", wa), ("b", wb)) if w is not None]
     packed = {}

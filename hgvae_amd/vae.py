@@ -343,9 +343,10 @@ def train_vae_custom_pool(model, loader, optimizer, clip_value=None, device=None
 
 
 def custom_pool_step_loss(model, x, edge_index, batch):
-    with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
-        reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
-    recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
+    with Fn.weight_images(model):
+        with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
+            reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
+        recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
     return recon_loss + model.beta * model.kl_divergence(mean, log_std)
 
 
@@ -384,7 +385,7 @@ def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     """Loss of one reference train step (no backward)."""
     share = getattr(model, "share_first_conv", None)
     # the loss looks at the reconstruction only: pooled graphs (pool variants) may stay at their capacity
-    with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling():
+    with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling(), Fn.weight_images(model):
         out = model(x, edge_index, batch)
         enc = model.encode(x, edge_index)
     mean, log_std = enc[-2], enc[-1]

@@ -303,7 +303,7 @@ int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1, int64_t ld
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
  * hgv_gemm_nt16_supported: 1 when the split image of an N x (K1 + K2) weight, whole or in two parts along N,
  * fits in LDS (then hgv_pack16_bytes > 0).  hgv_pack16_weights builds the image of [W1 | W2] (W2 nullable,
- * element (n,k) of source s at Ws[n*sn_s + k*sk_s]); hgv_pack16_weights_multi builds up to four images in one
+ * element (n,k) of source s at Ws[n*sn_s + k*sk_s]); hgv_pack16_weights_multi builds up to 24 images in one
  * launch (arrays of njobs entries; W2[q] may be null with K2[q] = 0); hgv_gemm_nt16 computes
  * C = A1 W1^T (+ A2 W2^T) (+ bias) under the contract of hgv_gemm_nt_packed (A, C 16-byte aligned, leading
  * dimensions multiples of 4) in one launch, whether the image has one part or two. */

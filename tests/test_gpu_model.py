@@ -524,3 +524,56 @@ def test_paired_first_level_equals_two_separate_epilogues(variant, monkeypatch):
     assert all(torch.equal(x, y) for x, y in zip(ga, gb))
     assert all(torch.equal(x, y) for x, y in zip(ba, bb))
     assert int(ba[2]) == 4          # encoder1's BatchNorm saw two batches per step
+
+
+def test_planned_weight_images_follow_every_parameter_change():
+    """Inside a loss evaluation the projection weights' images are packed by one launch from a plan recorded in the
+    previous evaluation.  The images must be those of the CURRENT weights however the weights were changed in between
+    (optimizer step, in-place edit through .data, load_state_dict), and the first evaluation (no plan yet) must give
+    the same numbers as later ones given the same weights and noise."""
+    import hgvae_amd
+    from hgvae_amd import functional as Fn
+    from hgvae_amd import synthetic
+    from hgvae_amd.vae import SkipconVAE, train_step_loss
+    dev = torch.device("cuda:0")
+    batch = synthetic.path_graph_batch([138] * 4, 60, seed=3, device=dev)
+
+    def evaluate(model):
+        hgvae_amd.manual_seed(21)
+        model.zero_grad()
+        loss = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+        loss.backward()
+        return loss.detach().clone(), [p.grad.clone() for p in model.parameters()]
+
+    torch.manual_seed(0)
+    model = SkipconVAE(60, 138, 28).to(dev).train()
+    first = evaluate(model)                                   # records the plan
+    assert getattr(model, "_hgv_image_plan_grad", None)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    # change the weights in ways that leave Tensor._version alone or replace contents wholesale
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.mul_(1.01)
+    changed = evaluate(model)                                 # planned images, new weights
+    torch.manual_seed(0)
+    fresh = SkipconVAE(60, 138, 28).to(dev).train()
+    fresh.load_state_dict(model.state_dict())                 # same weights, no plan
+    want = evaluate(fresh)
+    assert torch.equal(changed[0], want[0]) and all(torch.equal(a, b) for a, b in zip(changed[1], want[1]))
+    assert not torch.equal(changed[0], first[0])
+    model.load_state_dict(state)                              # back to the first weights (BatchNorm buffers included)
+    fresh2 = SkipconVAE(60, 138, 28).to(dev).train()
+    fresh2.load_state_dict(state)
+    again, want2 = evaluate(model), evaluate(fresh2)
+    assert torch.equal(again[0], want2[0]) and all(torch.equal(a, b) for a, b in zip(again[1], want2[1]))
+    # evaluation mode keeps a plan of its own (no transposed images)
+    model.eval()
+    with torch.no_grad():
+        train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+        a = train_step_loss(model, batch.x, batch.edge_index, batch.batch, 1.0)
+    with Fn.direct_weight_grads(False):
+        fresh2.eval()
+        with torch.no_grad():
+            b = train_step_loss(fresh2, batch.x, batch.edge_index, batch.batch, 1.0)
+    assert len(model._hgv_image_plan_nograd) < len(model._hgv_image_plan_grad)
+    assert torch.isfinite(a) and torch.isfinite(b)
