@@ -19,6 +19,7 @@
 // keep probability quantised to 1/65536): the integer multiplies of the generator, not memory,
 // bounded these kernels when every 4 elements paid for a call of their own.
 #include "common.h"
+#include <stdlib.h>
 #include <mutex>
 
 namespace {
@@ -618,8 +619,10 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
     a.mask = mask; a.seed = seed; a.offset = offset; a.offset2 = 0; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
-    // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread
-    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * 4);
+    // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread - two rows per
+    // thread for small matrices, where the launch is as long as its longest workgroup (4 416 x 138: 4 % of a captured step
+    // against 4 rows; one row per thread is slower again at width 256)
+    int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * (N >= 32768 ? 4 : 2));
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
     a.rows_per_block = hgv_cdiv(N, nb);
