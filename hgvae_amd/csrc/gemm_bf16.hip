@@ -928,7 +928,7 @@ Tn16Plan tn16_plan(int64_t M, int N, int K1, int K2) {
     const int per = p.ngrps * p.kgrps;
     int64_t sets = cu_count16() / per;
     if (sets < 1) sets = 1;
-    if (sets > p.steps / 4) sets = p.steps / 4;
+    if (sets > p.steps / 2) sets = p.steps / 2;        // at least two 32-row steps per workgroup (a few thousand rows: 2 % of a captured step against four)
     p.sets = (int)sets;
     const double live = (double)N * (K1 + K2) / ((double)per * 144 * 144);
     p.ok = N > 0 && K1 > 0 && K2 >= 0 && p.sets >= 1 && live >= 0.6 && p.ngrps <= 2;
