@@ -526,6 +526,11 @@ int raise_lds16(Kern kern) {
     return HGV_OK;
 }
 
+// Fewest waves per workgroup: every workgroup first copies its weight image (up to 160 KB) into LDS, which two waves do
+// in eight rounds of loads and four waves in four; with a few hundred row tiles in all (a 4 416-row batch) that copy is
+// most of the launch (4 waves: 3.5 % of the captured chignolin step against 1-2; 8 the same, 12 slower).
+constexpr int nt_min_waves() { return 4; }
+
 template <int NT>
 int launch_nt16(const Nt16Args& a, int part, size_t lds, hipStream_t st) {
     auto kern = k_gemm_nt16<NT>;
@@ -534,6 +539,7 @@ int launch_nt16(const Nt16Args& a, int part, size_t lds, hipStream_t st) {
     // one workgroup per compute unit; as many waves (<= 16) as there are tiles to hand out
     const int cus = cu_count16();
     int64_t wpb = hgv_cdiv(a.ntiles, cus);
+    if (wpb < nt_min_waves()) wpb = nt_min_waves();
     if (wpb > nt16_waves<NT>()) wpb = nt16_waves<NT>();
     if (wpb < 1) wpb = 1;
     int64_t blocks = hgv_cdiv(a.ntiles, wpb);
@@ -589,6 +595,7 @@ int launch_nt16_pair(Nt16Args a, size_t lds, hipStream_t st) {
     if (rc != HGV_OK) return rc;
     const int cus = cu_count16();
     int64_t wpb = hgv_cdiv(a.ntiles, cus / 2 > 0 ? cus / 2 : 1);
+    if (wpb < nt_min_waves()) wpb = nt_min_waves();
     if (wpb > nt16_waves<NT0>()) wpb = nt16_waves<NT0>();
     if (wpb < 1) wpb = 1;
     // Share of the compute units per part: a wave's time is (rounds of row tiles) x (cost of one row
