@@ -68,7 +68,24 @@ class FlatGradBucket:
             off += n
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.branch_flat: Optional[torch.Tensor] = None
         self.attach()
+
+    def enable_branch(self) -> None:
+        """A second flat buffer for the part of a step that runs on a branch stream next to the rest (the second
+        encode pass of a captured step): its kernels add weight gradients there instead of racing with the trunk's
+        adds into ``p.grad``; :meth:`merge_branch` folds it into the bucket after backward."""
+        if self.branch_flat is None:
+            self.branch_flat = torch.zeros_like(self.flat)
+            off = 0
+            for p in self.params:
+                n = p.numel()
+                p._hgv_branch_grad = self.branch_flat[off:off + n].view_as(p)
+                off += n
+
+    def merge_branch(self) -> None:
+        if self.branch_flat is not None:
+            self.flat.add_(self.branch_flat)
 
     def attach(self) -> None:
         """Point every ``p.grad`` at its slice of the flat buffer (autograd then accumulates in place)."""
@@ -78,6 +95,8 @@ class FlatGradBucket:
     def zero(self) -> None:
         """Replacement for ``optimizer.zero_grad()`` that keeps the views alive."""
         self.flat.zero_()
+        if self.branch_flat is not None:
+            self.branch_flat.zero_()
         self.attach()
 
     def gather(self) -> None:

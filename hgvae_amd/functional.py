@@ -320,7 +320,7 @@ def weight_images(owner):
             keys.append((_wkey(wa), _wkey(wb), t))
     if jobs:
         for key, img in zip(keys, _pack_split(jobs)):
-            scope.images[key] = img
+            scope.images[key] = (img, None)        # packed before anything else of the evaluation: valid on every stream
     prev, _image_scope = _image_scope, scope
     try:
         yield
@@ -349,8 +349,8 @@ def _images(*specs) -> list:
                 if key not in scope.requests:
                     scope.requests[key] = (_wref(wa), _wref(wb) if wb is not None else None, t)
                 hit = scope.images.get(key)
-                if hit is not None:
-                    out[i] = hit
+                if hit is not None and (hit[1] is None or hit[1] == _lib.stream()):
+                    out[i] = hit[0]
                     continue
             split.append((i, wa, wb, t, n, k1, k2))
         else:
@@ -360,7 +360,7 @@ def _images(*specs) -> list:
         for (i, wa, wb, t, _n, _k1, _k2), img in zip(split, imgs):
             out[i] = img
             if scope is not None and _plannable(wa) and _plannable(wb):      # the second encode pass reuses it
-                scope.images[(_wkey(wa), _wkey(wb), t)] = img
+                scope.images[(_wkey(wa), _wkey(wb), t)] = (img, _lib.stream())
     # fp32 images: two weights per image at most, four weights per launch
     flat = [(i, which, w, t) for (i, wa, wb, t) in plain for (which, w) in (("a", wa), ("b", wb)) if w is not None]
     packed = {}
@@ -417,10 +417,35 @@ def direct_weight_grads(enabled: bool = True):
         _direct_grads = prev
 
 
+_trunk_stream: Optional[int] = None      # raw handle of the stream the step runs on while part of it runs on a branch stream
+
+
+@contextlib.contextmanager
+def branch_of(trunk: "torch.cuda.Stream"):
+    """Marks the operators created inside (with another stream current) as a branch next to ``trunk``: in their
+    backward pass - which autograd runs on the branch stream, possibly at the same time as the trunk's - weight and
+    bias gradients are returned to autograd instead of being added into ``.grad`` by the kernels (see
+    :func:`direct_weight_grads`), and weight images packed on the spot are not shared across the two streams."""
+    global _trunk_stream
+    _trunk_stream = trunk.cuda_stream      # stays set after the context: the backward pass comes later
+    yield
+
+
+def no_branches() -> None:
+    """The evaluation that starts now runs on one stream (forgets the trunk of an earlier branched evaluation)."""
+    global _trunk_stream
+    _trunk_stream = None
+
+
 def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """``p.grad`` when gradients may be accumulated into it in place, else None."""
     if not _direct_grads or p is None or not p.is_leaf or not p.requires_grad:
         return None
+    if _trunk_stream is not None and _lib.stream() != _trunk_stream:
+        # a branch stream: adds into .grad would race with the trunk's.  The bucket's branch buffer if there is one
+        # (FlatGradBucket.enable_branch), else back to autograd, which orders the two
+        tw = getattr(p, "_hgv_branch_grad", None)
+        return tw if tw is not None and tw.shape == p.shape and tw.device == p.device else None
     g = p.grad
     if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or g.device != p.device:
         return None

@@ -13,6 +13,7 @@ that depend only on the batch vector are cached per batch tensor during the warm
 """
 from __future__ import annotations
 
+import warnings
 from typing import Callable, Optional
 
 import torch
@@ -39,6 +40,7 @@ class GraphedTrainStep:
         self.model, self.optimizer = model, optimizer
         self.x, self.edge_index, self.batch, self.lambda_kl, self.loss_fn = x, edge_index, batch, lambda_kl, loss_fn
         self.bucket = bucket if bucket is not None else FlatGradBucket(model.parameters())
+        self.bucket.enable_branch()
         dev = x.device
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.noise = PhiloxNoise(seed, device_counter=self.counter)
@@ -76,8 +78,12 @@ class GraphedTrainStep:
         self.bucket.zero()
         with use_noise(self.noise):
             loss = self.loss_fn(self.model, self.x, self.edge_index, self.batch, self.lambda_kl)
-        with direct_weight_grads():
+        with direct_weight_grads(), warnings.catch_warnings():
+            # the second encode pass is a branch on a stream of its own under capture; its weight gradients reach the
+            # accumulation nodes of the capture stream from there, on purpose
+            warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
             loss.backward()
+        self.bucket.merge_branch()
         if reduce:
             self.bucket.all_reduce_mean()
         if step_optimizer:

@@ -10,6 +10,7 @@ statistics: the arithmetic of each level runs in fused HIP kernels
 from __future__ import annotations
 
 import contextlib
+import os
 import weakref
 from typing import Optional
 
@@ -136,7 +137,11 @@ class SkipconVAE(_VAEBase):
         y = conv(x, g)
         pair = Fn.bn_act_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
         if pair is not None:
-            memo[:] = [x, g, torch.is_grad_enabled(), ("levels", pair[1])]
+            done = None
+            if _two_streams(y.size(0)):  # the second pass may start here, next to the rest of the first
+                done = torch.cuda.Event()
+                done.record()
+            memo[:] = [x, g, torch.is_grad_enabled(), ("levels", pair[1]), done]
             return pair[0]
         y, y_again = Fn.fork(y)
         memo[:] = [x, g, torch.is_grad_enabled(), ("preact", y_again)]
@@ -381,13 +386,62 @@ def train_vae(model, loader, optimizer, lambda_kl=1.0):
     return float(total.item()) / len(loader)
 
 
+# The second encode pass on a stream of its own: "capture" (default) while a HIP graph is being captured - the two
+# passes become parallel branches of the graph, which a batch of a few thousand nodes needs to fill the chip (its
+# kernels occupy a fraction of the CUs each: captured chignolin step 0.85 -> 0.71 ms) - "always", or "never".  Eager
+# steps of that size are bound by the host, and large batches fill the chip with every kernel (measured: no gain).
+_branch_streams = os.environ.get("HGVAE_BRANCH_STREAMS", "capture")
+_side_streams: dict = {}
+
+
+def set_branch_streams(mode: str) -> None:
+    global _branch_streams
+    if mode not in ("capture", "always", "never"):
+        raise ValueError("branch streams: 'capture', 'always' or 'never'")
+    _branch_streams = mode
+
+
+BRANCH_MAX_ROWS = 65536      # beyond this every kernel fills the chip by itself and the branch only adds bookkeeping
+
+
+def _two_streams(n_rows: int) -> bool:
+    if _branch_streams == "never":
+        return False
+    if _branch_streams == "always":
+        return True
+    return n_rows <= BRANCH_MAX_ROWS and torch.cuda.is_current_stream_capturing()
+
+
+def _side_stream(device):
+    s = _side_streams.get(device.index)
+    if s is None:
+        s = _side_streams[device.index] = torch.cuda.Stream(device)
+    return s
+
+
 def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     """Loss of one reference train step (no backward)."""
     share = getattr(model, "share_first_conv", None)
+    Fn.no_branches()
     # the loss looks at the reconstruction only: pooled graphs (pool variants) may stay at their capacity
     with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling(), Fn.weight_images(model):
         out = model(x, edge_index, batch)
-        enc = model.encode(x, edge_index)
+        memo = getattr(model, "_conv1_memo", None)
+        if memo and len(memo) > 4 and memo[4] is not None:
+            # second pass as a branch of its own: it needs the paired first level only.  Its operators allocate from
+            # the side stream's pool and its backward nodes run there (autograd keeps a node on its forward stream)
+            main = torch.cuda.current_stream()
+            side = _side_stream(x.device)
+            side.wait_event(memo[4])
+            for t in memo[3][1]:
+                t.record_stream(side)
+            with torch.cuda.stream(side), Fn.branch_of(main):
+                enc = model.encode(x, edge_index)
+            for t in enc:
+                t.record_stream(main)
+            main.wait_stream(side)
+        else:
+            enc = model.encode(x, edge_index)
     mean, log_std = enc[-2], enc[-1]
     recon_loss = Fn.mse_loss(out[0], padded_input(x))
     kl_loss = model.kl_divergence(mean, log_std)

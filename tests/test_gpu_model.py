@@ -577,3 +577,36 @@ def test_planned_weight_images_follow_every_parameter_change():
             b = train_step_loss(fresh2, batch.x, batch.edge_index, batch.batch, 1.0)
     assert len(model._hgv_image_plan_nograd) < len(model._hgv_image_plan_grad)
     assert torch.isfinite(a) and torch.isfinite(b)
+
+
+@pytest.mark.parametrize("variant", ["skipcon", "attention"])
+def test_captured_step_with_the_second_pass_on_a_branch_stream(variant):
+    """Under capture the second encode pass is a parallel branch of the graph.  Same noise, same kernels, same
+    per-stream workspaces: parameters after three replays equal those of a capture without the branch up to the
+    order in which the two passes' weight gradients are added."""
+    import hgvae_amd
+    from hgvae_amd import synthetic, vae
+    from hgvae_amd.graphed import GraphedTrainStep
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.vae import SkipconAttentionVAE, SkipconVAE
+    dev = torch.device("cuda:0")
+    batch = synthetic.path_graph_batch([138] * 8, 60, seed=5, device=dev)
+    finals = []
+    try:
+        for mode in ("never", "capture"):
+            vae.set_branch_streams(mode)
+            torch.manual_seed(0)
+            model = (SkipconVAE(60, 138, 28) if variant == "skipcon" else SkipconAttentionVAE(60, 64, 28)).to(dev).train()
+            opt = FlatAdam(model.parameters(), lr=1e-3)
+            step = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, bucket=opt.bucket, seed=31)
+            losses = [float(step()) for _ in range(3)]
+            torch.cuda.synchronize()
+            finals.append((losses, torch.cat([p.detach().flatten() for p in model.parameters()]).clone(),
+                           [b.clone() for b in model.buffers()]))
+    finally:
+        vae.set_branch_streams("capture")
+    (la, pa, ba), (lb, pb, bb) = finals
+    assert all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(la, lb)), (la, lb)
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pa.abs().max())
+    for x, y in zip(ba, bb):
+        assert torch.allclose(x.double(), y.double(), rtol=1e-5, atol=1e-7)
