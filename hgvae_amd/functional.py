@@ -435,6 +435,29 @@ def no_branches() -> None:
     """The evaluation that starts now runs on one stream (forgets the trunk of an earlier branched evaluation)."""
     global _trunk_stream
     _trunk_stream = None
+    _branch_updates.clear()
+
+
+def on_branch_stream() -> bool:
+    return _trunk_stream is not None and _lib.stream() != _trunk_stream
+
+
+_branch_updates: list = []      # (BatchNorm module, [2, H] stand-in holding momentum * (mean, unbiased variance), momentum)
+
+
+def apply_branch_updates() -> None:
+    """Running-statistics updates that the branch deferred; call on the trunk stream after the branch has joined."""
+    import numpy as np
+    for bn, stand_in, momentum in _branch_updates:
+        keep = float(np.float32(1.0) - np.float32(momentum))          # the kernel's (1.f - momentum)
+        with torch.no_grad():
+            if bn.running_mean is not None:
+                bn.running_mean.mul_(keep).add_(stand_in[0])
+            if bn.running_var is not None:
+                bn.running_var.mul_(keep).add_(stand_in[1])
+            if bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+    _branch_updates.clear()
 
 
 def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -958,6 +981,14 @@ def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, trai
     if p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
+    if on_branch_stream():
+        # The trunk may be updating this module's running statistics at this moment (the other encode pass).  The
+        # kernel updates a zeroed stand-in instead - which leaves momentum * statistic there - and the real buffers
+        # take (1 - momentum) * buffer + stand-in after the branch has joined: the bits of two updates in program order.
+        stand_in = torch.zeros(2, y.size(1), dtype=torch.float32, device=y.device)
+        _branch_updates.append((bn, stand_in, momentum))
+        return _BnAct.apply(y, bn.weight, bn.bias, stand_in[0], stand_in[1], relu, p, mask, seed, offset, ctr,
+                            bn.eps, momentum, None, fork)
     # num_batches_tracked is incremented by the statistics kernel
     return _BnAct.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, mask, seed, offset, ctr,
                         bn.eps, momentum, bn.num_batches_tracked, fork)

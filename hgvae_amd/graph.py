@@ -237,8 +237,12 @@ def graph_of(edge_index, num_nodes: Optional[int] = None) -> Graph:
     if num_nodes is None:
         raise _lib.HgvError("num_nodes is required to build a Graph")
     g = Graph(edge_index, num_nodes, hold=False)
+    g.by_dst.long_rows(g.num_nodes)
     if torch.is_grad_enabled():
-        g.by_src  # built now: the caller's tensor may be gone by the time backward runs
+        # built now: the caller's tensor may be gone by the time backward runs - and everything the backward pass reads
+        # exists before any of it can run on a second stream
+        g.by_src.long_rows(g.num_nodes)
+        g.inv_deg
     ref = weakref.ref(edge_index, lambda _r, k=key: _cache.pop(k, None))
     _cache[key] = (ref, edge_index._version, num_nodes, g)
     return g

@@ -440,6 +440,7 @@ def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
             for t in enc:
                 t.record_stream(main)
             main.wait_stream(side)
+            Fn.apply_branch_updates()
         else:
             enc = model.encode(x, edge_index)
     mean, log_std = enc[-2], enc[-1]
