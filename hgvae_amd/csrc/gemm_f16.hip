@@ -1,0 +1,744 @@
+// Projections on the fp16 matrix cores with scaled two-piece operands ("f16x3").
+//
+// Same operator contract as hgv_gemm_nt16 (gvae/gvae_skipcon.py:61-100):
+//   C[M,N] = A1[M,K1] W1^T (+ A2[M,K2] W2^T) (+ bias)
+// Every fp32 operand x is scaled by a power of two s so that the largest entry of its row lands in
+// [2^12, 2^13) and split into two fp16 pieces y = x s = h + l + r (h = fp16(y), l = fp16(y - h), both
+// round-to-nearest: |r| <= 2^-22 |y|).  The product is formed from the three significant piece products
+//   al*wh + ah*wl + ah*wh        (each one v_mfma_f32_16x16x32_f16, fp32 accumulation, small terms first)
+// and the accumulator is multiplied by 1 / (s_a s_w) at the end, which is exact.  The dropped terms are
+// <= 3 * 2^-22 |a w| per product (the bf16 six-product kernel drops 2^-23): half the matrix-core work and a
+// quarter of the splitting instructions of that kernel at an error that stays below 1e-6 of the sum of |terms|.
+//
+// Scales.  W: one scale per output row n, computed by the packing kernel and stored (as its inverse) behind the
+// image.  A: one scale per row and tile, chosen by the wave while it streams the row: the scale of a tile starts from
+// the largest entry of the row's first 32-wide k chunk and is lowered - accumulators multiplied by the ratio, a power
+// of two - whenever a later chunk would exceed 2^15 with it (fp16 overflows at 2^16).  Entries far below the row's
+// largest keep an absolute accuracy of 2^-25 (fp16 subnormal spacing) on the 2^12 scale, i.e. 2^-37 of the row maximum.
+// Layout of the image, LDS residency, the two-part launch and its pacing are those of the bf16 kernel.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr size_t LDSH_MAX = 160 * 1024;
+
+struct GeoH {
+    int N, K1, K2;
+    int nb1, nb2;        // 8-column blocks per source
+    int chunks;          // 32-wide k chunks over the concatenation
+    int tiles;           // n tiles (16 columns each)
+    int parts, tpp;      // parts along N, n tiles per part (last part may hold fewer)
+    int rows;            // image rows per part: 16 tpp, or N for a single part stored without the dead rows of its last n tile
+    int stream;          // 1: the image does not fit even in two parts: 32-wide k chunks are streamed through LDS
+};
+
+__host__ __device__ inline size_t part_bytes_h(int rows, int chunks) { return (size_t)chunks * 2 * rows * 64; }
+// table + bias row + inverse weight scales live in LDS next to the image
+__host__ __device__ inline size_t side_bytes_h(int chunks, int nt) { return (size_t)chunks * 64 + 2 * (size_t)nt * 16 * 4; }
+
+inline bool geo_h(int N, int K1, int K2, GeoH* g) {
+    g->N = N; g->K1 = K1; g->K2 = K2;
+    g->nb1 = (K1 + 7) / 8; g->nb2 = (K2 + 7) / 8;
+    g->chunks = (g->nb1 + g->nb2 + 3) / 4;
+    g->tiles = (N + 15) / 16;
+    g->stream = 0;
+    // whole; whole without the dead rows of the last n tile (138 rows of 9 x 16: the 138+138 -> 138 image then fits and
+    // the rows of A are streamed once instead of once per part); two parts along N
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        const int parts = attempt == 2 ? 2 : 1;
+        const int tpp = (g->tiles + parts - 1) / parts;
+        const int rows = attempt == 1 ? N : tpp * 16;
+        if (tpp <= 9 && part_bytes_h(rows, g->chunks) + side_bytes_h(g->chunks, 9) + 256 <= LDSH_MAX) {
+            g->parts = parts; g->tpp = tpp; g->rows = rows;
+            return true;
+        }
+    }
+    static const int widths[] = {2, 4, 6, 9, 12, 16, 18};
+    for (int w : widths) {
+        if (w >= g->tiles && (size_t)2 * 2 * w * 1024 + side_bytes_h(g->chunks, w) + 256 <= LDSH_MAX) {
+            g->parts = 1; g->tpp = w; g->rows = w * 16; g->stream = 1;
+            return true;
+        }
+    }
+    return false;
+}
+
+// scale 2^(12 - floor(log2 amax)) and its inverse; amax >= 0.  Rows of zeros (or below 2^-115) get 2^127 and an
+// inverse of zero, infinities the smallest scale.
+__device__ __forceinline__ float scale_for(float amax, float& inv) {
+    const unsigned e = __float_as_uint(amax) >> 23;
+    const unsigned se = min(266u - e, 254u);
+    inv = __uint_as_float((254u - se) << 23);
+    return __uint_as_float(se << 23);
+}
+
+struct PackHArgs {
+    const float* W1; int64_t sn1, sk1; const float* W2; int64_t sn2, sk2;
+    GeoH g;
+    _Float16* out;
+};
+
+constexpr int PACKH_MAX_JOBS = 24;
+struct PackHJobs {
+    PackHArgs job[PACKH_MAX_JOBS];
+    int first_block[PACKH_MAX_JOBS + 1];
+    int njobs;
+};
+
+// One wave per image row (part, r): largest |w| of the row, then the two scaled pieces of every element.
+__global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
+    int q = 0;
+#pragma unroll
+    for (int j = 1; j < PACKH_MAX_JOBS; ++j)
+        if (j < jobs.njobs && (int)blockIdx.x >= jobs.first_block[j]) q = j;
+    const PackHArgs& a = jobs.job[q];
+    const GeoH& g = a.g;
+    const int slots = g.tpp * 16;                                 // output rows per part; the image holds the first g.rows of them
+    const int R = ((int)blockIdx.x - jobs.first_block[q]) * 4 + (int)(threadIdx.x >> 6);
+    if (R >= g.parts * slots) return;
+    const int lane = threadIdx.x & 63;
+    const int part = R / slots, r = R - part * slots;
+    const int n = R;
+    const int rows = g.rows;
+    float amax = 0.f;
+    if (n < g.N) {
+        for (int k = lane; k < g.K1; k += 64) amax = fmaxf(amax, __builtin_fabsf(a.W1[(int64_t)n * a.sn1 + (int64_t)k * a.sk1]));
+        for (int k = lane; k < g.K2; k += 64) amax = fmaxf(amax, __builtin_fabsf(a.W2[(int64_t)n * a.sn2 + (int64_t)k * a.sk2]));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    float inv;
+    const float s = scale_for(amax, inv);
+    const size_t piece_elems = (size_t)rows * 32;
+    _Float16* img = a.out + (size_t)part * g.chunks * 2 * piece_elems;
+    for (int e = lane; e < (r < rows ? g.chunks * 32 : 0); e += 64) {
+        const int c = e >> 5, kk = e & 31;
+        const int blk = 4 * c + (kk >> 3), j = kk & 7;
+        float x = 0.f;
+        if (n < g.N) {
+            if (blk < g.nb1) { const int k = 8 * blk + j; if (k < g.K1) x = a.W1[(int64_t)n * a.sn1 + (int64_t)k * a.sk1]; }
+            else if (blk < g.nb1 + g.nb2) { const int k = 8 * (blk - g.nb1) + j; if (k < g.K2) x = a.W2[(int64_t)n * a.sn2 + (int64_t)k * a.sk2]; }
+        }
+        const float y = x * s;
+        const _Float16 h = (_Float16)y;
+        const _Float16 l = (_Float16)(y - (float)h);
+        const int piece = (kk >> 3) ^ ((r & 8) ? 3 : 0);
+        const size_t base = (size_t)c * 2 * piece_elems + (size_t)r * 32 + piece * 8 + j;
+        img[base] = h;
+        img[base + piece_elems] = l;
+    }
+    if (lane == 0) {
+        float* invw = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.out) + (size_t)g.parts * part_bytes_h(g.rows, g.chunks));
+        invw[R] = n < g.N ? inv : 0.f;
+    }
+}
+
+struct NtHArgs {
+    const float* A1; int64_t lda1; const float* A2; int64_t lda2;
+    GeoH g;
+    const _Float16* Wp; const float* bias;
+    float* C; int64_t ldc; int64_t M;
+    int64_t ntiles;
+    int wgs0;
+    int paced;
+};
+
+// Progress counters of paced two-part launches (hints only: a stale value costs time, never correctness).
+constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
+constexpr int64_t PACE_MIN_BYTES = (int64_t)256 << 20;
+__device__ int pace_ctr_h[2 * PACE_WGS * PACE_WAVES];
+
+#ifndef NTH_WAVES_WIDE
+#define NTH_WAVES_WIDE 12
+#endif
+#ifndef NTH_RING_WIDE
+#define NTH_RING_WIDE 4
+#endif
+template <int NT> constexpr int nth_waves() { return NT > 6 ? NTH_WAVES_WIDE : 16; }
+template <int NT> constexpr int nth_ring() { return NT > 6 ? NTH_RING_WIDE : 4; }
+
+struct SplitH { f16x8 h, l; };
+
+// largest |x| of the 8 values of this lane and of the three other lanes that hold the same row (lanes i, i+16, i+32, i+48)
+__device__ __forceinline__ float row_amax(const f32x4 (&av)[2]) {
+    float m = fmaxf(fmaxf(__builtin_fabsf(av[0][0]), __builtin_fabsf(av[0][1])), fmaxf(__builtin_fabsf(av[0][2]), __builtin_fabsf(av[0][3])));
+    m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(av[1][0]), __builtin_fabsf(av[1][1])), fmaxf(__builtin_fabsf(av[1][2]), __builtin_fabsf(av[1][3]))));
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+
+__device__ __forceinline__ void split2(float x, float s, _Float16& h, _Float16& l) {
+    const float y = x * s;
+    h = (_Float16)y;
+    l = (_Float16)(y - (float)h);
+}
+
+__device__ __forceinline__ SplitH split8h(const f32x4 (&av)[2], float s) {
+    SplitH o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        _Float16 h, l;
+        split2(av[j >> 2][j & 3], s, h, l);
+        o.h[j] = h; o.l[j] = l;
+    }
+    return o;
+}
+
+template <int NT, int RING>
+__device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
+    const GeoH& g = a.g;
+    const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(t >> 6), wpb = blockDim.x >> 6;
+    const int t0 = part * g.tpp;
+    const int rows = g.rows;                                       // rows per piece image
+    const size_t img = part_bytes_h(rows, g.chunks);
+    int4* tab = reinterpret_cast<int4*>(lds_raw + img);
+    float* bias_s = reinterpret_cast<float*>(lds_raw + img + (size_t)g.chunks * 64);
+    float* invw_s = bias_s + NT * 16;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)part * img);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
+        const int npieces = (int)(img / 16);
+        for (int e0 = t; e0 < npieces; e0 += 8 * blockDim.x) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * (int)blockDim.x, npieces - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * (int)blockDim.x < npieces) dst[e0 + u * (int)blockDim.x] = v[u];
+        }
+        for (int e = t; e < g.chunks * 4; e += blockDim.x) {
+            int second = 0, col = 0; int64_t ld = a.lda1;
+            if (e < g.nb1) { col = 8 * e; }
+            else if (e < g.nb1 + g.nb2) { second = 1; col = 8 * (e - g.nb1); ld = a.lda2; }
+            // both 16-byte halves stay inside the row's leading dimension (columns past K meet zero weights)
+            const int c0 = (int)min((int64_t)col, ld - 4), c1 = (int)min((int64_t)col + 4, ld - 4);
+            tab[e] = make_int4(c0 * 4, c1 * 4, second, 0);
+        }
+        const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)g.parts * img);
+        for (int e = t; e < NT * 16; e += blockDim.x) {
+            const int n = t0 * 16 + e;
+            bias_s[e] = (a.bias && n < g.N) ? a.bias[n] : 0.f;
+            invw_s[e] = invw[t0 * 16 + e];
+        }
+    }
+    __syncthreads();
+
+    const int64_t gw = (int64_t)wib * wgs + wg_rank, nw = (int64_t)wpb * wgs;
+    const int64_t my_tiles = gw < a.ntiles ? (a.ntiles - gw + nw - 1) / nw : 0;
+    const int steps = g.chunks;
+
+    f32x4 acc[NT];
+    // per-lane LDS byte offset of (row i, swizzled piece kq) inside a piece image; the last n tile of an image stored
+    // without its dead rows reads the last stored row instead (those outputs are never stored)
+    const int wlane = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
+    const int row_last = min(16 * (NT - 1) + i, rows - 1);
+    const int wlane_last = row_last * 64 + ((kq ^ ((row_last & 8) ? 3 : 0)) * 16);
+
+    // pacing of two-part launches: see k_gemm_nt16_pair
+    int* pace_mine = pace_ctr_h + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    const int* pace_twin = pace_ctr_h + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    bool pace = a.paced != 0;
+    int pace_step = 0;
+    int pace_seen[RING];
+#pragma unroll
+    for (int d = 0; d < RING; ++d) pace_seen[d] = 0;
+    auto pace_gate = [&](int d) __attribute__((always_inline)) {
+        if (lane == 0) __hip_atomic_store(pace_mine, pace_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__builtin_amdgcn_readfirstlane(pace_seen[(d + RING - 2) % RING]) < pace_step - (PACE_AHEAD + 2)) {
+            for (int spin = 0;; ++spin) {
+                const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (seen >= pace_step - PACE_AHEAD) break;
+                if (spin >= PACE_SPINS) { pace = false; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        pace_seen[d] = __hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++pace_step;
+    };
+
+    int64_t ltile = gw, lidx = 0; int lq = 0;
+    const char *lp1, *lp2;
+    auto row_pointers = [&]() __attribute__((always_inline)) {
+        const int64_t row = min(ltile * 16 + i, a.M - 1);
+        lp1 = reinterpret_cast<const char*>(a.A1 + row * a.lda1);
+        lp2 = reinterpret_cast<const char*>((a.A2 ? a.A2 : a.A1) + row * (a.A2 ? a.lda2 : a.lda1));
+    };
+    f32x4 ring[RING][2];
+    int4 e_next = tab[kq];
+    auto issue = [&](int d) __attribute__((always_inline)) {
+        if (pace) pace_gate(d);
+        const int4 e = e_next;
+        const char* p = e.z ? lp2 : lp1;
+        ring[d][0] = *reinterpret_cast<const f32x4*>(p + e.x);
+        ring[d][1] = *reinterpret_cast<const f32x4*>(p + e.y);
+        if (++lq == steps) {
+            lq = 0;
+            if (lidx + 1 < my_tiles) { ++lidx; ltile += nw; row_pointers(); }
+        }
+        e_next = tab[lq * 4 + kq];
+    };
+    // n tiles in groups of GS: the three piece products of a group are issued term by term across its tiles, so
+    // MFMAs that depend on each other are GS instructions apart; the next step's operand is split (with the scale
+    // s_next) in the shadow of this step's MFMAs, SPR elements behind every row of MFMAs.
+    constexpr int GS = (NT % 3 == 0 || NT > 4) ? 3 : (NT > 1 ? 2 : 1);
+    constexpr int MROWS = 3 * ((NT + GS - 1) / GS);
+    constexpr int SPR = (8 + MROWS - 1) / MROWS;
+    auto compute = [&](const SplitH& cur, const f32x4 (&av_next)[2], int c, float s_next) __attribute__((always_inline)) {
+        const unsigned char* base = lds_raw + (size_t)c * 2 * rows * 64;
+        SplitH nxt;
+        int el = 0;          // compile-time after unrolling: elements of the next operand split so far
+#pragma unroll
+        for (int n0 = 0; n0 < NT; n0 += GS) {
+            f16x8 wh[GS], wl[GS];
+#pragma unroll
+            for (int j = 0; j < GS; ++j) {
+                if (n0 + j < NT) {
+                    const unsigned char* w = n0 + j == NT - 1 ? base + wlane_last : base + wlane + (size_t)(n0 + j) * 16 * 64;
+                    wh[j] = *reinterpret_cast<const f16x8*>(w);
+                    wl[j] = *reinterpret_cast<const f16x8*>(w + (size_t)rows * 64);
+                }
+            }
+#define HGV_TERM(WP, AP)                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < GS; ++j)                                                        \
+                if (n0 + j < NT) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WP[j], AP, acc[n0 + j], 0, 0, 0); \
+            _Pragma("unroll") for (int u = 0; u < SPR; ++u) {                                                     \
+                if (el < 8) {                                                                                      \
+                    _Float16 h_, l_;                                                                               \
+                    float x_ = av_next[el >> 2][el & 3];                                                           \
+                    asm volatile("" : "+v"(x_));                                                                   \
+                    split2(x_, s_next, h_, l_);                                                                    \
+                    nxt.h[el] = h_; nxt.l[el] = l_;                                                                \
+                }                                                                                                  \
+                ++el;                                                                                              \
+            }                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0x180);
+            HGV_TERM(wl, cur.h) HGV_TERM(wh, cur.l) HGV_TERM(wh, cur.h)
+#undef HGV_TERM
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= el) {
+                _Float16 h_, l_;
+                split2(av_next[j >> 2][j & 3], s_next, h_, l_);
+                nxt.h[j] = h_; nxt.l[j] = l_;
+            }
+        }
+        return nxt;
+    };
+
+    if (my_tiles > 0) {
+        row_pointers();
+#pragma unroll
+        for (int d = 0; d < RING; ++d) issue(d);
+    }
+    int64_t ctile = gw;
+    int cq = 0;
+    const int64_t S = my_tiles * steps;
+    SplitH cur;
+    float s_cur = 1.f, inv_cur = 1.f;          // scale of the lane's row in the tile being accumulated
+    if (my_tiles > 0) {
+        const f32x4 av0[2] = {ring[0][0], ring[0][1]};
+        s_cur = scale_for(row_amax(av0), inv_cur);
+        cur = split8h(av0, s_cur);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t u0 = 0; u0 < S; u0 += RING) {
+#pragma unroll
+        for (int d = 0; d < RING; ++d) {
+            issue(d);
+            if (u0 + d < S) {
+                const f32x4 av_next[2] = {ring[(d + 1) % RING][0], ring[(d + 1) % RING][1]};
+                // scale of the next step: a new tile starts from its first chunk; inside a tile the scale only ever
+                // goes down, when the chunk would leave the fp16 range with the current one
+                const bool fresh = cq + 1 == steps;
+                const float amax = row_amax(av_next);
+                const bool grow = amax * s_cur > 32768.f;
+                float inv_t;
+                const float s_t = scale_for(amax, inv_t);
+                const bool take = fresh || grow;
+                const float s_next = take ? s_t : s_cur, inv_next = take ? inv_t : inv_cur;
+                cur = compute(cur, av_next, cq, s_next);
+                if (fresh) {
+                    // weights as the row operand: lane (i, kq) register r = C[row i][16 n + 4 kq + r]
+                    const int64_t row = ctile * 16 + i;
+                    if (row < a.M) {
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            const int col = (t0 + n) * 16 + 4 * kq;
+                            if (col < a.ldc) {
+                                const f32x4 iw = *reinterpret_cast<const f32x4*>(&invw_s[16 * n + 4 * kq]);
+                                const f32x4 bs = *reinterpret_cast<const f32x4*>(&bias_s[16 * n + 4 * kq]);
+                                f32x4 o;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] = (acc[n][r] * inv_cur) * iw[r] + bs[r];
+                                *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
+                            }
+                        }
+                    }
+                    cq = 0; ctile += nw;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    ++cq;
+                    if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                        const float ratio = s_next * inv_cur;          // 1 for the rows that keep their scale
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[n][r] *= ratio;
+                    }
+                }
+                s_cur = s_next; inv_cur = inv_next;
+            }
+        }
+    }
+    if (a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    nth_body<NT, nth_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
+}
+
+template <int NT0, int NT1>
+__global__ __launch_bounds__(64 * nth_waves<NT0>()) void k_gemm_nt16h_pair(const NtHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if ((int)blockIdx.x < a.wgs0) nth_body<NT0, nth_ring<NT0>()>(a, lds_raw, 0, blockIdx.x, a.wgs0);
+    else nth_body<NT1, nth_ring<NT1>()>(a, lds_raw, 1, (int)blockIdx.x - a.wgs0, (int)gridDim.x - a.wgs0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Weights whose image does not fit in LDS (hidden width 256): 12 waves own one row tile each and all NT n tiles of
+// it; the 32-wide k chunks of the image are copied by all threads into one of two LDS buffers while the waves
+// multiply from the other (one barrier per chunk).  The scale of a row is fixed per row block the same way as above.
+template <int NT>
+__global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const GeoH& g = a.g;
+    const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int ROWS = NT * 16, CHUNK_BYTES = 2 * ROWS * 64, UNITS = CHUNK_BYTES / 16, UPT = (UNITS + 767) / 768;
+    int4* tab = reinterpret_cast<int4*>(lds_raw + 2 * CHUNK_BYTES);
+    float* bias_s = reinterpret_cast<float*>(lds_raw + 2 * CHUNK_BYTES + (size_t)g.chunks * 64);
+    float* invw_s = bias_s + ROWS;
+    for (int e = t; e < g.chunks * 4; e += 768) {
+        int second = 0, col = 0; int64_t ld = a.lda1;
+        if (e < g.nb1) { col = 8 * e; }
+        else if (e < g.nb1 + g.nb2) { second = 1; col = 8 * (e - g.nb1); ld = a.lda2; }
+        const int c0 = (int)min((int64_t)col, ld - 4), c1 = (int)min((int64_t)col + 4, ld - 4);
+        tab[e] = make_int4(c0 * 4, c1 * 4, second, 0);
+    }
+    {
+        const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + part_bytes_h(g.rows, g.chunks));
+        for (int e = t; e < ROWS; e += 768) {
+            bias_s[e] = (a.bias && e < g.N) ? a.bias[e] : 0.f;
+            invw_s[e] = invw[e];
+        }
+    }
+    const f32x4* img = reinterpret_cast<const f32x4*>(a.Wp);
+    f32x4 wst[UPT];
+    auto w_load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) wst[u] = img[(size_t)c * UNITS + min(t + 768 * u, UNITS - 1)];
+    };
+    auto w_store = [&](int b) __attribute__((always_inline)) {
+        f32x4* dst = reinterpret_cast<f32x4*>(lds_raw + b * CHUNK_BYTES);
+#pragma unroll
+        for (int u = 0; u < UPT; ++u)
+            if (t + 768 * u < UNITS) dst[t + 768 * u] = wst[u];
+    };
+    const int64_t nblocks = (a.ntiles + 11) / 12;
+    const int chunks = g.chunks;
+    const int wlane = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
+
+    w_load(0);
+    w_store(0);
+    __syncthreads();
+
+    f32x4 a_nx[2];
+    auto a_load = [&](int64_t rb, int c) __attribute__((always_inline)) {
+        const int64_t row = min((rb * 12 + wib) * 16 + i, a.M - 1);
+        const int4 e = tab[c * 4 + kq];
+        const char* p = e.z ? reinterpret_cast<const char*>(a.A2 + row * a.lda2) : reinterpret_cast<const char*>(a.A1 + row * a.lda1);
+        a_nx[0] = *reinterpret_cast<const f32x4*>(p + e.x);
+        a_nx[1] = *reinterpret_cast<const f32x4*>(p + e.y);
+    };
+    int buf = 0;
+    if ((int64_t)blockIdx.x < nblocks) a_load(blockIdx.x, 0);
+    for (int64_t rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float s_cur = 1.f, inv_cur = 1.f;
+        for (int c = 0; c < chunks; ++c) {
+            const int cn = c + 1 < chunks ? c + 1 : 0;
+            w_load(cn);
+            {
+                const float amax = row_amax(a_nx);
+                const bool grow = amax * s_cur > 32768.f;
+                if (c == 0) {
+                    s_cur = scale_for(amax, inv_cur);
+                } else if (__builtin_amdgcn_ballot_w64(grow) != 0) {
+                    float inv_t;
+                    const float s_t = scale_for(amax, inv_t);
+                    const float s_next = grow ? s_t : s_cur;
+                    const float ratio = s_next * inv_cur;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[n][r] *= ratio;
+                    inv_cur = grow ? inv_t : inv_cur;
+                    s_cur = s_next;
+                }
+            }
+            const SplitH cur = split8h(a_nx, s_cur);
+            {
+                const int64_t rbn = c + 1 < chunks ? rb : (rb + gridDim.x < nblocks ? rb + gridDim.x : rb);
+                a_load(rbn, cn);
+            }
+            const unsigned char* base = lds_raw + buf * CHUNK_BYTES + wlane;
+            constexpr int GS = 3;
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += GS) {
+                f16x8 wh[GS], wl[GS];
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    if (n0 + j < NT) {
+                        const unsigned char* w = base + (size_t)(n0 + j) * 16 * 64;
+                        wh[j] = *reinterpret_cast<const f16x8*>(w);
+                        wl[j] = *reinterpret_cast<const f16x8*>(w + (size_t)ROWS * 64);
+                    }
+                }
+#define HGV_S_TERM(WP, AP)                                                                                         \
+                _Pragma("unroll") for (int j = 0; j < GS; ++j)                                                    \
+                    if (n0 + j < NT) acc[n0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WP[j], AP, acc[n0 + j], 0, 0, 0);
+                HGV_S_TERM(wl, cur.h) HGV_S_TERM(wh, cur.l) HGV_S_TERM(wh, cur.h)
+#undef HGV_S_TERM
+            }
+            w_store(buf ^ 1);
+            buf ^= 1;
+            __syncthreads();
+        }
+        const int64_t tile = rb * 12 + wib;
+        const int64_t row = tile * 16 + i;
+        if (tile < a.ntiles && row < a.M) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = n * 16 + 4 * kq;
+                if (col < a.ldc) {
+                    const f32x4 iw = *reinterpret_cast<const f32x4*>(&invw_s[16 * n + 4 * kq]);
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(&bias_s[16 * n + 4 * kq]);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (acc[n][r] * inv_cur) * iw[r] + bs[r];
+                    *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
+                }
+            }
+        }
+    }
+}
+
+int cu_count_h() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
+template <typename Kern>
+int raise_lds_h(Kern kern) {
+    static bool raised[64] = {false};          // one instance per kernel type
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!raised[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)LDSH_MAX);
+        HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "gemm_nt16h: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+        raised[dev] = true;
+    }
+    return HGV_OK;
+}
+
+constexpr int nth_min_waves() { return 4; }
+
+template <int NT>
+int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
+    auto kern = k_gemm_nt16h<NT>;
+    const int rc = raise_lds_h(kern);
+    if (rc != HGV_OK) return rc;
+    const int cus = cu_count_h();
+    int64_t wpb = hgv_cdiv(a.ntiles, cus);
+    if (wpb < nth_min_waves()) wpb = nth_min_waves();
+    if (wpb > nth_waves<NT>()) wpb = nth_waves<NT>();
+    int64_t blocks = hgv_cdiv(a.ntiles, wpb);
+    if (blocks > cus) blocks = cus;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), lds, st, a, part);
+    return HGV_OK;
+}
+
+int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t st) {
+    switch (nt) {
+        case 1: return launch_nth<1>(a, part, lds, st);
+        case 2: return launch_nth<2>(a, part, lds, st);
+        case 3: return launch_nth<3>(a, part, lds, st);
+        case 4: return launch_nth<4>(a, part, lds, st);
+        case 5: return launch_nth<5>(a, part, lds, st);
+        case 6: return launch_nth<6>(a, part, lds, st);
+        case 7: return launch_nth<7>(a, part, lds, st);
+        case 8: return launch_nth<8>(a, part, lds, st);
+        default: return launch_nth<9>(a, part, lds, st);
+    }
+}
+
+template <int NT>
+int launch_nths_nt(const NtHArgs& a, hipStream_t st) {
+    auto kern = k_gemm_nt16hs<NT>;
+    const int rc = raise_lds_h(kern);
+    if (rc != HGV_OK) return rc;
+    const size_t lds = (size_t)2 * 2 * NT * 1024 + side_bytes_h(a.g.chunks, NT);
+    int64_t blocks = hgv_cdiv(a.ntiles, 12);
+    if (blocks > cu_count_h()) blocks = cu_count_h();
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(768), lds, st, a);
+    return HGV_OK;
+}
+
+int launch_nths(const NtHArgs& a, hipStream_t st) {
+    switch (a.g.tpp) {
+        case 2: return launch_nths_nt<2>(a, st);
+        case 4: return launch_nths_nt<4>(a, st);
+        case 6: return launch_nths_nt<6>(a, st);
+        case 9: return launch_nths_nt<9>(a, st);
+        case 12: return launch_nths_nt<12>(a, st);
+        case 16: return launch_nths_nt<16>(a, st);
+        case 18: return launch_nths_nt<18>(a, st);
+        default: return HGV_EUNSUPPORTED;
+    }
+}
+
+// Both parts in one launch; every part streams all row tiles of A (share of the compute units and pacing as for the
+// bf16 kernel: the cost of a row tile grows slowly with the part's width).
+template <int NT0, int NT1>
+int launch_nth_pair(NtHArgs a, size_t lds, hipStream_t st) {
+    auto kern = k_gemm_nt16h_pair<NT0, NT1>;
+    const int rc = raise_lds_h(kern);
+    if (rc != HGV_OK) return rc;
+    const int cus = cu_count_h();
+    int64_t wpb = hgv_cdiv(a.ntiles, cus / 2 > 0 ? cus / 2 : 1);
+    if (wpb < nth_min_waves()) wpb = nth_min_waves();
+    if (wpb > nth_waves<NT0>()) wpb = nth_waves<NT0>();
+    int share0 = cus / 2;
+    const int64_t a_bytes = a.M * 4 * (a.lda1 + (a.A2 ? a.lda2 : 0));
+    const bool paced = a_bytes >= PACE_MIN_BYTES && cus % 16 == 0 && cus / 2 <= PACE_WGS && wpb <= PACE_WAVES &&
+                       hgv_cdiv(a.ntiles, wpb) >= cus / 2 && a.ntiles < ((int64_t)1 << 31);
+    a.paced = paced ? 1 : 0;
+    if (!paced) {
+        int64_t best = -1;
+        const int lo = cus / 4 > 0 ? cus / 4 : 1;
+        for (int s0 = lo; s0 <= cus - lo && s0 < cus; ++s0) {
+            const int64_t r0 = hgv_cdiv(a.ntiles, (int64_t)s0 * wpb), r1 = hgv_cdiv(a.ntiles, (int64_t)(cus - s0) * wpb);
+            const int64_t c0 = r0 * (11 + NT0), c1 = r1 * (11 + NT1);
+            const int64_t c = c0 > c1 ? c0 : c1;
+            const int d = s0 > cus / 2 ? s0 - cus / 2 : cus / 2 - s0, dbest = share0 > cus / 2 ? share0 - cus / 2 : cus / 2 - share0;
+            if (best < 0 || c < best || (c == best && d < dbest)) { best = c; share0 = s0; }
+        }
+    }
+    const int share1 = cus - share0;
+    const int64_t want = hgv_cdiv(a.ntiles, wpb);
+    const int wgs0 = (int)(want < share0 ? want : share0), wgs1 = (int)(want < share1 ? want : share1);
+    a.wgs0 = wgs0;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wgs0 + wgs1)), dim3((unsigned)(64 * wpb)), lds, st, a);
+    return HGV_OK;
+}
+
+int launch_nth_both(const NtHArgs& a, int nt0, int nt1, size_t lds, hipStream_t st) {
+#define HGV_PAIR(N0)                                                                                   \
+    case N0: return nt1 == N0 ? launch_nth_pair<N0, N0>(a, lds, st) : launch_nth_pair<N0, (N0 > 1 ? N0 - 1 : 1)>(a, lds, st);
+    switch (nt0) {
+        HGV_PAIR(1) HGV_PAIR(2) HGV_PAIR(3) HGV_PAIR(4) HGV_PAIR(5) HGV_PAIR(6) HGV_PAIR(7) HGV_PAIR(8) HGV_PAIR(9)
+        default: return HGV_EUNSUPPORTED;
+    }
+#undef HGV_PAIR
+}
+
+}  // namespace
+
+// 1 when hgv_gemm_nt16h can run this shape
+extern "C" int hgv_gemm_nt16h_supported(int N, int K1, int K2) {
+    GeoH g;
+    return (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g)) ? 1 : 0;
+}
+
+// image (two fp16 pieces per element) followed by one inverse scale per image row
+extern "C" size_t hgv_pack16h_bytes(int N, int K1, int K2) {
+    GeoH g;
+    if (!(N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g))) return 0;
+    return hgv_align256(part_bytes_h(g.rows, g.chunks) * g.parts + (size_t)g.parts * g.tpp * 16 * 4);
+}
+
+// Up to 24 images in one launch: job q packs [W1[q] | W2[q]] (W2[q] may be null, then K2[q] = 0) into out[q].
+extern "C" int hgv_pack16h_weights_multi(int njobs, const float* const* W1, const int64_t* sn1, const int64_t* sk1, const int* K1,
+                                         const float* const* W2, const int64_t* sn2, const int64_t* sk2, const int* K2,
+                                         const int* N, void* const* out, hipStream_t stream) {
+    HGV_REQUIRE(njobs >= 1 && njobs <= PACKH_MAX_JOBS && W1 && sn1 && sk1 && K1 && W2 && sn2 && sk2 && K2 && N && out, HGV_EINVAL,
+                "pack16h_weights_multi: 1..%d jobs and non-null arrays expected", PACKH_MAX_JOBS);
+    PackHJobs jobs{};
+    jobs.njobs = njobs;
+    int blocks = 0;
+    for (int q = 0; q < njobs; ++q) {
+        PackHArgs& a = jobs.job[q];
+        HGV_REQUIRE(W1[q] && out[q] && N[q] > 0 && K1[q] > 0 && (W2[q] ? K2[q] > 0 : K2[q] == 0), HGV_EINVAL, "pack16h_weights: bad arguments");
+        HGV_REQUIRE(geo_h(N[q], K1[q], K2[q], &a.g), HGV_EUNSUPPORTED, "pack16h_weights: %d x (%d + %d) does not fit in LDS", N[q], K1[q], K2[q]);
+        HGV_REQUIRE(hgv_aligned(out[q], 16), HGV_EINVAL, "pack16h_weights: output must be 16-byte aligned");
+        a.W1 = W1[q]; a.sn1 = sn1[q]; a.sk1 = sk1[q]; a.W2 = W2[q]; a.sn2 = sn2[q]; a.sk2 = sk2[q]; a.out = (_Float16*)out[q];
+        jobs.first_block[q] = blocks;
+        blocks += (a.g.parts * a.g.tpp * 16 + 3) / 4;
+    }
+    for (int q = njobs; q <= PACKH_MAX_JOBS; ++q) jobs.first_block[q] = blocks;
+    hipLaunchKernelGGL(k_pack16h, dim3((unsigned)blocks), dim3(256), 0, stream, jobs);
+    HGV_CHECK_LAUNCH("pack16h_weights");
+    return HGV_OK;
+}
+
+// C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
+extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                              const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
+    HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
+    if (M == 0) return HGV_OK;
+    NtHArgs a{};
+    HGV_REQUIRE(geo_h(N, K1, A2 ? K2 : 0, &a.g), HGV_EUNSUPPORTED, "gemm_nt16h: %d x (%d + %d) does not fit in LDS", N, K1, K2);
+    HGV_REQUIRE(A1 && hgv_aligned(A1, 16) && lda1 % 4 == 0 && lda1 >= (K1 + 3) / 4 * 4 && Wp && hgv_aligned(Wp, 16), HGV_EINVAL,
+                "gemm_nt16h: bad/misaligned buffer (source 1)");
+    if (A2) HGV_REQUIRE(K2 > 0 && hgv_aligned(A2, 16) && lda2 % 4 == 0 && lda2 >= (K2 + 3) / 4 * 4, HGV_EINVAL,
+                        "gemm_nt16h: bad/misaligned buffer (source 2)");
+    HGV_REQUIRE(C && hgv_aligned(C, 16) && ldc % 4 == 0 && ldc >= N, HGV_EINVAL, "gemm_nt16h: bad/misaligned output");
+    a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const _Float16*)Wp; a.bias = bias;
+    a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
+    int rc;
+    if (a.g.stream) {
+        rc = launch_nths(a, stream);
+    } else {
+        const size_t lds = part_bytes_h(a.g.rows, a.g.chunks) + side_bytes_h(a.g.chunks, 9);
+        if (a.g.parts == 1) {
+            rc = launch_nth_part(a, 0, a.g.tiles, lds, stream);
+        } else {
+            const int nt1 = a.g.tiles - a.g.tpp;
+            HGV_REQUIRE(nt1 >= 1 && (nt1 == a.g.tpp || nt1 == a.g.tpp - 1), HGV_EUNSUPPORTED, "gemm_nt16h: unexpected split %d + %d", a.g.tpp, nt1);
+            rc = launch_nth_both(a, a.g.tpp, nt1, lds, stream);
+        }
+    }
+    if (rc != HGV_OK) return rc;
+    HGV_CHECK_LAUNCH("gemm_nt16h");
+    return HGV_OK;
+}

@@ -177,12 +177,16 @@ def _pack(*specs):
 # error as the fp32 MFMA chain, ~1.5x faster); "fp32" keeps v_mfma_f32_16x16x4_f32.  Shapes whose
 # split weight image does not fit in LDS use the fp32 kernels either way.
 _projection = os.environ.get("HGVAE_PROJECTION", "bf16x6")
+# "f16x3": the same products from two scaled fp16 pieces per operand and three piece products (half the matrix-core
+# work; dropped terms <= 3 * 2^-22 per product instead of 2^-23).
+_SPLIT_KINDS = {"bf16x6": ("hgv_gemm_nt16_supported", "hgv_pack16_bytes", "hgv_pack16_weights_multi", "hgv_gemm_nt16"),
+                "f16x3": ("hgv_gemm_nt16h_supported", "hgv_pack16h_bytes", "hgv_pack16h_weights_multi", "hgv_gemm_nt16h")}
 
 
 def set_projection(kind: str) -> None:
     global _projection
-    if kind not in ("bf16x6", "fp32"):
-        raise ValueError("projection arithmetic is 'bf16x6' or 'fp32'")
+    if kind not in ("bf16x6", "f16x3", "fp32"):
+        raise ValueError("projection arithmetic is 'bf16x6', 'f16x3' or 'fp32'")
     _projection = kind
 
 
@@ -192,11 +196,12 @@ _split_sizes: dict = {}
 
 def _split_image_floats(n: int, k1: int, k2: int) -> int:
     """Size (in floats) of the split-bf16 image of an n x (k1 + k2) weight, 0 when the NT kernel does not take the shape."""
-    key = (n, k1, k2)
+    key = (_projection, n, k1, k2)
     v = _split_sizes.get(key)
     if v is None:
         lib = _lib.load()
-        v = _split_sizes[key] = lib.hgv_pack16_bytes(n, k1, k2) // 4 if lib.hgv_gemm_nt16_supported(n, k1, k2) else 0
+        supported, nbytes, _, _ = _SPLIT_KINDS[_projection]
+        v = _split_sizes[key] = getattr(lib, nbytes)(n, k1, k2) // 4 if getattr(lib, supported)(n, k1, k2) else 0
     return v
 
 
@@ -237,14 +242,14 @@ def _pack_split(jobs) -> list:
         for q, ((wa, wb, t, n, k1, k2), sz) in enumerate(zip(part, sizes)):
             piece = buf[off:off + sz]
             off += sz
-            out.append(_Image("bf16x6", piece))
+            out.append(_Image(_projection, piece))
             W1[q], Op[q] = wa.data_ptr(), piece.data_ptr()
             sn1[q], sk1[q] = (wa.stride(1), wa.stride(0)) if t else (wa.stride(0), wa.stride(1))
             if wb is not None:
                 W2[q] = wb.data_ptr()
                 sn2[q], sk2[q] = (wb.stride(1), wb.stride(0)) if t else (wb.stride(0), wb.stride(1))
             K1[q], K2[q], N[q] = k1, k2, n
-        _lib.call("hgv_pack16_weights_multi", nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
+        _lib.call(_SPLIT_KINDS[_projection][2], nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
     return out
 
 
@@ -302,7 +307,7 @@ def weight_images(owner):
     of the next evaluation.  Nothing outlives the context except the plan (weak references and shapes), so an image
     can never be older than the evaluation that uses it.  Only leaf parameters are planned."""
     global _image_scope
-    if _projection != "bf16x6":
+    if _projection not in _SPLIT_KINDS:
         yield
         return
     attr = "_hgv_image_plan_grad" if torch.is_grad_enabled() else "_hgv_image_plan_nograd"
@@ -343,7 +348,7 @@ def _images(*specs) -> list:
         wa, wb, t = sp
         n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
         k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
-        if _projection == "bf16x6" and _split_image_floats(n, k1, k2) > 0:
+        if _projection in _SPLIT_KINDS and _split_image_floats(n, k1, k2) > 0:
             if scope is not None and _plannable(wa) and _plannable(wb):
                 key = (_wkey(wa), _wkey(wb), t)
                 if key not in scope.requests:
@@ -385,8 +390,8 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     if ev:
         ev[0].record()
-    if img.kind == "bf16x6":
-        _lib.call("hgv_gemm_nt16", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
+    if img.kind in _SPLIT_KINDS:
+        _lib.call(_SPLIT_KINDS[img.kind][3], xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
                   ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
                   _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
     else:
@@ -478,7 +483,7 @@ def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 def _tn16_ok(m, n, k1, k2, *mats) -> bool:
     """Weight gradients run on the bf16 matrix cores (split operands, fp32-accurate) when the projection
     arithmetic is "bf16x6", the shape is one the kernel covers and the operands are 16-byte aligned."""
-    if _projection != "bf16x6" or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
+    if _projection not in _SPLIT_KINDS or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
         return False
     return all(t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 for t in mats)
 

@@ -317,6 +317,21 @@ int hgv_pack16_weights_multi(int njobs, const float* const* W1, const int64_t* s
 int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                   const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
 
+/* ---- the same projections on the fp16 matrix cores with scaled two-piece operands ("f16x3": every operand times a
+ *      power of two that brings its row's largest entry to [2^12, 2^13), split into two fp16 pieces, three piece
+ *      products per fp32 product, fp32 accumulation, exact rescaling at the end; dropped terms <= 3 * 2^-22 per
+ *      product).  Replaces the same reference calls as hgv_gemm_nt16 (the lin_l / lin_r / Linear products of
+ *      gvae/gvae_skipcon.py:61-100) at half its matrix-core work.  Same contracts as the hgv_*16 functions above;
+ *      the image holds two pieces per element plus one inverse scale per weight row.  Pad columns [K, lda) of A must
+ *      be zero (a large finite pad value would set the row's scale). */
+int hgv_gemm_nt16h_supported(int N, int K1, int K2);
+size_t hgv_pack16h_bytes(int N, int K1, int K2);
+int hgv_pack16h_weights_multi(int njobs, const float* const* W1, const int64_t* sn1, const int64_t* sk1, const int* K1,
+                              const float* const* W2, const int64_t* sn2, const int64_t* sk2, const int* K2, const int* N,
+                              void* const* out, hgv_stream_t stream);
+int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                   const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
+
 /* Weight gradients of the same projections on the bf16 matrix cores (three-piece split of both operands, six piece
  * products, fp32 accumulation per row slice, fp64 across slices): contract of hgv_gemm_tn2 with A2 / GW2 nullable, plus
  * 16-byte aligned G / A1 / A2 with leading dimensions that are multiples of 4.  hgv_gemm_tn16_supported: 1 for shapes
