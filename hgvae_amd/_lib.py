@@ -88,6 +88,8 @@ SIGNATURES = {
     "hgv_gemm_tn16_ws": (_sz, [_i64, _i32, _i32, _i32]),
     "hgv_gemm_tn16": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32,
                                 _vp, _sz, _vp]),
+    "hgv_gemm_tn16h": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32,
+                                 _vp, _sz, _vp]),
     "hgv_gemm_tn2": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i64, _vp, _i32,
                                _vp, _sz, _vp]),
     "hgv_loss_ws": (_sz, []),

@@ -851,6 +851,255 @@ __global__ __launch_bounds__(T16_THREADS) void k_gemm_tn16(const Tn16Args a) {
     else tn16_body<2>(a, lds_raw, wn, 1 + 2 * wk, wk == 1, false);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same weight gradient from two scaled fp16 pieces per operand and three piece products ("f16x3").
+// Both operands are reduced over their rows, so a scale has to be constant over the rows a workgroup adds up: each
+// workgroup keeps ONE power-of-two scale for its tiles of G and one for its tiles of A, such that the largest entry seen
+// so far sits in [2^12, 2^13).  Every wave publishes the largest |value| of the 32-row tile it has just loaded (LDS
+// atomic max, order-independent) one step before that tile is split, so the scale is exact, not predicted; when a
+// tile would leave the fp16 range with the running scale, the scale is lowered and the accumulators are multiplied by
+// the ratio (a power of two).  Entries within 2^-16 of the largest keep all 22 bits, smaller ones an absolute accuracy
+// of 2^-25 on the 2^12 scale.  Partial sets are written unscaled (multiplied by 1 / (s_g s_a), exact), so the
+// reduction kernel is shared with the bf16 path.  Staging layout and wave roles are those of k_gemm_tn16.
+typedef _Float16 f16x8t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4t __attribute__((ext_vector_type(4)));
+constexpr int T16H_BUF = 2 * T16_PIECE;
+constexpr int T16H_LDS = 2 * T16H_BUF + 64;
+
+__device__ __forceinline__ float scale_for_t(float amax, float& inv) {
+    const unsigned e = __float_as_uint(amax) >> 23;
+    const unsigned se = min(266u - e, 254u);
+    inv = __uint_as_float((254u - se) << 23);
+    return __uint_as_float(se << 23);
+}
+
+// largest value of a wave (all lanes receive it); x >= 0
+__device__ __forceinline__ float wave_max(float x) {
+    int v = __float_as_int(x);
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));     // row_mirror
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = max((int)r[0], (int)r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return __int_as_float(max((int)q[0], (int)q[1]));
+}
+
+__device__ __forceinline__ float amax4(const f32x4& v) {
+    return fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+}
+
+__device__ __forceinline__ f16x8t t16h_read(const unsigned char* lds, int addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(lds + addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)(lds + addr + 256));
+    union { struct { s16x4 a, b; } s; f16x8t v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+template <int KT>
+__device__ __forceinline__ void tn16h_body(const Tn16Args& a, unsigned char* lds, const int wn, const int k0t, const bool bias, const bool lead) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int per = a.ngrps * a.kgrps;
+    const int grp = a.paced ? (int)(blockIdx.x >> 3) & 1 : (int)(blockIdx.x % per);
+    const int set = a.paced ? (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7) : (int)(blockIdx.x / per);
+    const int ngrp = grp / a.kgrps, kgrp = grp - ngrp * a.kgrps;
+    const int second = kgrp >= a.kg0;
+    const int n_off = 144 * ngrp, k_off = 144 * (second ? kgrp - a.kg0 : kgrp);
+    const float* Ab = a.A[second]; const int64_t lda = a.lda[second];
+    const int n_w = min(144, a.N - n_off), k_w = min(144, a.K[second] - k_off);
+    const int64_t s_lo = a.steps * set / a.sets, s_hi = a.steps * (set + 1) / a.sets;
+    const float* src[3]; int64_t ld[3]; int waddr[3]; int srow[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int f = t + T16_THREADS * u;
+        const int isa = f >= 1152, rem = isa ? f - 1152 : f;
+        const int row = rem / 36, c4 = rem - 36 * row, col = 4 * c4;
+        const int width = isa ? k_w : n_w;
+        const int ceff = col < (width + 3) / 4 * 4 ? col : 0;
+        ld[u] = isa ? lda : a.ldg;
+        srow[u] = row;
+        src[u] = (isa ? Ab + k_off : a.G + n_off) + (int64_t)row * ld[u] + ceff;
+        waddr[u] = (isa * 9 + (col >> 4)) * T16_PANEL + t16_slot(row) * 32 + (col & 15) * 2;
+    }
+    // float4 u = 0 of every thread belongs to G, u = 2 to A, u = 1 to G in waves 0-5 and to A in waves 6-11
+    const bool mid_is_g = wave < 6;
+    unsigned* slot = reinterpret_cast<unsigned*>(lds + 2 * T16H_BUF);      // [3][2]: largest |G|, |A| of tile s in slot s % 3
+    // Two sets of staging registers: the tile split in step s (tile s + 1) was loaded two steps earlier and its largest
+    // value published one step earlier, so neither the publication nor the split ever waits for a load just issued.
+    f32x4 stage[2][3];
+    auto load_step = [&](int64_t s, int set_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) stage[set_][u] = *reinterpret_cast<const f32x4*>(src[u] + min(s * T16_ROWS, a.M - T16_ROWS) * ld[u]);
+    };
+    auto publish = [&](int64_t s, int set_) __attribute__((always_inline)) {
+        const float m0 = amax4(stage[set_][0]), m1 = amax4(stage[set_][1]), m2 = amax4(stage[set_][2]);
+        const float mg = wave_max(mid_is_g ? fmaxf(m0, m1) : m0), ma = wave_max(mid_is_g ? m2 : fmaxf(m1, m2));
+        if (lane == 0) {
+            unsigned* sl = slot + 2 * (int)(s % 3);
+            __hip_atomic_fetch_max(sl, __float_as_uint(mg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(sl + 1, __float_as_uint(ma), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    float sg = 1.f, sa = 1.f, ig = 1.f, ia = 1.f;        // running scales of G and A and their inverses (same in every thread)
+    // scale for tile s (published before the last barrier): lowered when the tile would pass 2^15; returns acc multipliers
+    auto consume = [&](float mg, float ma, bool first, float& rg, float& ra) __attribute__((always_inline)) {
+        rg = 1.f; ra = 1.f;
+        if (first || mg * sg > 32768.f) { float inv; const float sn = scale_for_t(mg, inv); rg = sn * ig; sg = sn; ig = inv; }
+        if (first || ma * sa > 32768.f) { float inv; const float sn = scale_for_t(ma, inv); ra = sn * ia; sa = sn; ia = inv; }
+    };
+    auto write_step = [&](int b, int64_t s, int set_) __attribute__((always_inline)) {
+        unsigned char* base = lds + b * T16H_BUF;
+        const int skip = (int)(s * T16_ROWS - min(s * T16_ROWS, a.M - T16_ROWS));
+        if (skip > 0) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (srow[u] < skip) stage[set_][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const float sc = u == 0 ? sg : (u == 2 ? sa : (mid_is_g ? sg : sa));
+            f16x4t h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float y = stage[set_][u][e] * sc;
+                const _Float16 hh = (_Float16)y;
+                h[e] = hh; l[e] = (_Float16)(y - (float)hh);
+            }
+            *reinterpret_cast<f16x4t*>(base + waddr[u]) = h;
+            *reinterpret_cast<f16x4t*>(base + T16_PIECE + waddr[u]) = l;
+        }
+    };
+    const int kq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int raddr = t16_slot(8 * kq + q) * 32 + p * 8;
+
+    f32x4 acc[3][KT], accb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f16x8t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (_Float16)1.0f;
+
+    if (t < 6) slot[t] = 0u;
+    __syncthreads();
+    if (s_lo < s_hi) {
+        load_step(s_lo, 0);
+        publish(s_lo, 0);
+    }
+    __syncthreads();
+    if (s_lo < s_hi) {
+        float rg, ra;
+        consume(__uint_as_float(slot[2 * (int)(s_lo % 3)]), __uint_as_float(slot[2 * (int)(s_lo % 3) + 1]), true, rg, ra);
+        write_step(0, s_lo, 0);
+        if (s_lo + 1 < s_hi) { load_step(s_lo + 1, 1); publish(s_lo + 1, 1); }
+        if (s_lo + 2 < s_hi) load_step(s_lo + 2, 0);
+    }
+    __syncthreads();
+    int* pace_mine = pace_tn + blockIdx.x * 16;
+    const int* pace_twin = pace_tn + (blockIdx.x ^ 8) * 16;
+    bool pace = a.paced != 0 && lead;
+    // step s with PAR = (s - s_lo) & 1: tile s + 1 sits in register set PAR ^ 1, tile s + 2 in set PAR
+    auto step = [&](int64_t s, const int PAR) __attribute__((always_inline)) {
+        const int b = PAR;
+        const unsigned char* base = lds + b * T16H_BUF;
+        int pace_seen = 0;
+        if (pace) pace_seen = __hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the next tile's largest values first: LDS answers in order, and the split below needs only these two
+        const int sn3 = (int)((s + 1) % 3);
+        const float mg_next = __uint_as_float(slot[2 * sn3]), ma_next = __uint_as_float(slot[2 * sn3 + 1]);
+        f16x8t g[3][2], x[KT][2];      // [tile][piece]
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i][pc] = t16h_read(base, pc * T16_PIECE + (3 * wn + i) * T16_PANEL + raddr);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) x[j][pc] = t16h_read(base, pc * T16_PIECE + (9 + k0t + j) * T16_PANEL + raddr);
+        }
+        // next step's tiles: scale (published a step ago), split and store into the other buffer while the matrix cores work
+        float rg = 1.f, ra = 1.f;
+        if (s + 1 < s_hi) {
+            consume(mg_next, ma_next, false, rg, ra);
+            write_step(b ^ 1, s + 1, PAR ^ 1);
+        }
+        if (t == 0) { slot[2 * (int)(s % 3)] = 0u; slot[2 * (int)(s % 3) + 1] = 0u; }      // read a step ago, published again two steps on
+        load_step(min(s + 3, s_hi - 1), PAR ^ 1);          // unconditional (past the end: the last tile again), so that waits stay counted
+        // three piece products, small terms first: gl*xh, gh*xl, gh*xh
+#define HGV_TNH_TERM(GP, XP)                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
+            _Pragma("unroll") for (int j = 0; j < KT; ++j)                                              \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g[i][GP], x[j][XP], acc[i][j], 0, 0, 0);
+        HGV_TNH_TERM(1, 0) HGV_TNH_TERM(0, 1) HGV_TNH_TERM(0, 0)
+#undef HGV_TNH_TERM
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int pc = 1; pc >= 0; --pc) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g[i][pc], ones, accb[i], 0, 0, 0);
+        }
+        if (rg != 1.f || ra != 1.f) {              // uniform: the next tile is accumulated on a lower scale
+            const float r2 = rg * ra;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] *= r2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accb[i][r] *= rg;
+            }
+        }
+        if (s + 2 < s_hi) publish(s + 2, PAR);
+        if (pace) {
+            const int done = (int)(s - s_lo) + 1;
+            if (lane == 0) __hip_atomic_store(pace_mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(pace_seen) < done - PACE_TN_AHEAD) {
+                for (int spin = 0;; ++spin) {
+                    const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen >= done - PACE_TN_AHEAD) break;
+                    if (spin >= PACE_SPINS) { pace = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        __syncthreads();
+    };
+    for (int64_t s = s_lo; s < s_hi; s += 2) {
+        step(s, 0);
+        if (s + 1 < s_hi) step(s + 1, 1);
+    }
+    if (a.paced != 0 && lead && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const float unscale = ig * ia;
+    float* out = a.partial + ((int64_t)grp * a.sets + set) * T16_SET_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(((3 * wn + i) * 9 + k0t + j) * 4 + r) * 64 + lane] = acc[i][j][r] * unscale;
+    if (bias && a.bias_partial && kgrp == 0) {
+        float* bo = a.bias_partial + ((int64_t)ngrp * a.sets + set) * (9 * 256);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bo[((3 * wn + i) * 4 + r) * 64 + lane] = accb[i][r] * ig;
+    }
+}
+
+__global__ __launch_bounds__(T16_THREADS) void k_gemm_tn16h(const Tn16Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wk = w / 3, wn = w - 3 * wk;
+    if (wk == 0) tn16h_body<3>(a, lds_raw, wn, 0, false, w == 0);
+    else tn16h_body<2>(a, lds_raw, wn, 1 + 2 * wk, wk == 1, false);
+}
+
 struct Tr16Args {
     Tn16Args t;
     float* GW[2]; int64_t ldgw[2];
@@ -1025,9 +1274,9 @@ extern "C" size_t hgv_gemm_tn16_ws(int64_t M, int N, int K1, int K2) {
 }
 
 // GW1[N,K1] (+)= G^T A1, GW2[N,K2] (+)= G^T A2 (A2 / GW2 null for a single product), gbias[N] (+)= column sums of G.
-extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
-                             const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
-                             int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+static int gemm_tn16_any(bool f16, const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                        const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
+                        int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (!A2) K2 = 0;
     HGV_REQUIRE(M > 0 && N > 0 && K1 > 0 && (A2 ? K2 > 0 && GW2 : true), HGV_EINVAL, "gemm_tn16: bad sizes");
     const Tn16Plan p = tn16_plan(M, N, K1, K2);
@@ -1048,13 +1297,33 @@ extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1
                M * ldg * 4 >= tn_pace_min_bytes()) ? 1 : 0;
     a.partial = (float*)ws;
     a.bias_partial = gbias ? (float*)((char*)ws + hgv_align256((size_t)p.ngrps * p.kgrps * p.sets * T16_SET_FLOATS * 4)) : nullptr;
-    const size_t lds = 2 * T16_BUF;
-    const int rc = raise_lds16(k_gemm_tn16);
-    if (rc != HGV_OK) return rc;
-    hipLaunchKernelGGL(k_gemm_tn16, dim3((unsigned)(p.ngrps * p.kgrps * p.sets)), dim3(T16_THREADS), lds, stream, a);
+    if (f16) {
+        const int rc = raise_lds16(k_gemm_tn16h);
+        if (rc != HGV_OK) return rc;
+        hipLaunchKernelGGL(k_gemm_tn16h, dim3((unsigned)(p.ngrps * p.kgrps * p.sets)), dim3(T16_THREADS), (size_t)T16H_LDS, stream, a);
+    } else {
+        const size_t lds = 2 * T16_BUF;
+        const int rc = raise_lds16(k_gemm_tn16);
+        if (rc != HGV_OK) return rc;
+        hipLaunchKernelGGL(k_gemm_tn16, dim3((unsigned)(p.ngrps * p.kgrps * p.sets)), dim3(T16_THREADS), lds, stream, a);
+    }
     r.GW[0] = GW1; r.ldgw[0] = ldgw1; r.GW[1] = GW2; r.ldgw[1] = ldgw2; r.gbias = gbias; r.accumulate = accumulate;
     const int64_t elems = (int64_t)p.ngrps * p.kgrps * T16_SET_FLOATS + (gbias ? (int64_t)p.ngrps * 9 * 256 : 0);
     hipLaunchKernelGGL(k_reduce_tn16, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn16");
     return HGV_OK;
+}
+
+extern "C" int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                             const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
+                             int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return gemm_tn16_any(false, G, ldg, N, A1, lda1, K1, GW1, ldgw1, A2, lda2, K2, GW2, ldgw2, M, gbias, accumulate, ws, ws_bytes, stream);
+}
+
+// The same weight gradients from two scaled fp16 pieces per operand (three piece products); shapes, workspace and buffer
+// rules of hgv_gemm_tn16.  Pad columns [N, ldg) / [K, lda) must be zero (they take part in the scale).
+extern "C" int hgv_gemm_tn16h(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                              const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
+                              int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return gemm_tn16_any(true, G, ldg, N, A1, lda1, K1, GW1, ldgw1, A2, lda2, K2, GW2, ldgw2, M, gbias, accumulate, ws, ws_bytes, stream);
 }

@@ -172,15 +172,20 @@ def _pack(*specs):
     return out
 
 
-# Projection arithmetic: "bf16x6" (default) runs fp32-accurate products on the bf16 matrix cores
-# (every operand split into three bf16 pieces, six piece products, fp32 accumulation: same measured
-# error as the fp32 MFMA chain, ~1.5x faster); "fp32" keeps v_mfma_f32_16x16x4_f32.  Shapes whose
-# split weight image does not fit in LDS use the fp32 kernels either way.
-_projection = os.environ.get("HGVAE_PROJECTION", "bf16x6")
-# "f16x3": the same products from two scaled fp16 pieces per operand and three piece products (half the matrix-core
-# work; dropped terms <= 3 * 2^-22 per product instead of 2^-23).
+# Projection arithmetic.  "f16x3" (default): every operand is scaled by a power of two (per row of A, per row of W;
+# per workgroup in the weight gradients) and split into two fp16 pieces, three piece products on the fp16 matrix
+# cores, fp32 accumulation, exact rescaling: dropped terms <= 3 * 2^-22 per product, measured error at or below the
+# other two kinds.  "bf16x6": three bf16 pieces per operand, six piece products (no scaling, twice the matrix-core
+# work).  "fp32" keeps v_mfma_f32_16x16x4_f32.  Shapes whose split weight image does not fit in LDS use the fp32
+# kernels either way.
+_DEFAULT_PROJECTION = os.environ.get("HGVAE_PROJECTION", "f16x3")
+_projection = _DEFAULT_PROJECTION
 _SPLIT_KINDS = {"bf16x6": ("hgv_gemm_nt16_supported", "hgv_pack16_bytes", "hgv_pack16_weights_multi", "hgv_gemm_nt16"),
                 "f16x3": ("hgv_gemm_nt16h_supported", "hgv_pack16h_bytes", "hgv_pack16h_weights_multi", "hgv_gemm_nt16h")}
+
+
+def default_projection() -> str:
+    return _DEFAULT_PROJECTION
 
 
 def set_projection(kind: str) -> None:
@@ -480,9 +485,19 @@ def _grad_buffer(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return g
 
 
+def _tn16_name() -> str:
+    return "hgv_gemm_tn16h" if _projection == "f16x3" and _tn_f16 else "hgv_gemm_tn16"
+
+
+# Weight gradients of "f16x3" stay on the three-piece bf16 kernel by default: the fp16 kernel has ONE scale per workgroup
+# and operand (both operands are reduced over their rows), so a column more than 2^16 below the largest entry of its
+# 144-column group loses bits, and inside the train step it is only 2 % faster.  HGVAE_TN_F16=1 selects it.
+_tn_f16 = os.environ.get("HGVAE_TN_F16", "0") == "1"
+
+
 def _tn16_ok(m, n, k1, k2, *mats) -> bool:
-    """Weight gradients run on the bf16 matrix cores (split operands, fp32-accurate) when the projection
-    arithmetic is "bf16x6", the shape is one the kernel covers and the operands are 16-byte aligned."""
+    """Weight gradients run on the 16-bit matrix cores (split operands, fp32-accurate) when the projection
+    arithmetic is a split kind, the shape is one the kernel covers and the operands are 16-byte aligned."""
     if _projection not in _SPLIT_KINDS or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
         return False
     return all(t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 for t in mats)
@@ -505,7 +520,7 @@ def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out
         ev[0].record()
     if _tn16_ok(m, n, k, 0, g, x):
         ws = _workspace(_lib.load().hgv_gemm_tn16_ws(m, n, k, 0), g.device, "gemm_tn")
-        _lib.call("hgv_gemm_tn16", g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, gw.data_ptr(), gw.stride(0),
+        _lib.call(_tn16_name(), g.data_ptr(), ld_of(g), n, x.data_ptr(), ld_of(x), k, gw.data_ptr(), gw.stride(0),
                   None, 0, 0, None, 0, m, _lib.ptr(gb), 1 if accumulate else 0, ws.data_ptr(), ws.numel(), _lib.stream())
     else:
         ws = _workspace(_lib.load().hgv_gemm_tn_ws(m, n, k), g.device, "gemm_tn")
@@ -536,7 +551,7 @@ def _gemm_tn2(g, xa, xb, want_bias: bool, out_a=None, out_b=None, bias_out=None,
     ev = _probe.add("tn", (m, n, ka + kb)) if _probe is not None else None
     if ev:
         ev[0].record()
-    _lib.call("hgv_gemm_tn16" if tn16 else "hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
+    _lib.call(_tn16_name() if tn16 else "hgv_gemm_tn2", g.data_ptr(), ld_of(g), n, xa.data_ptr(), ld_of(xa), ka, ga.data_ptr(), ga.stride(0),
               xb.data_ptr(), ld_of(xb), kb, gb_.data_ptr(), gb_.stride(0), m, _lib.ptr(gbias), 1 if accumulate else 0,
               ws.data_ptr(), ws.numel(), _lib.stream())
     if ev:

@@ -342,6 +342,13 @@ int hgv_gemm_tn16(const float* G, int64_t ldg, int N, const float* A1, int64_t l
                   const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
                   void* ws, size_t ws_bytes, hgv_stream_t stream);
 
+/* hgv_gemm_tn16 from two scaled fp16 pieces per operand and three piece products (one power-of-two scale per workgroup
+ * and operand, lowered while the rows stream by); same shapes (hgv_gemm_tn16_supported), workspace (hgv_gemm_tn16_ws) and
+ * buffer rules; pad columns of G / A must be zero. */
+int hgv_gemm_tn16h(const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
+                   const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
+                   void* ws, size_t ws_bytes, hgv_stream_t stream);
+
 /* ---- clustering export: pairwise distances of the atoms of one structure (scipy.spatial.distance_matrix at
  *      gvae/gvae_skipcon.py:352-354, float64) ----------------------------------------------------------------------
  * coords [n, dim] float64 (dim 1..4, contiguous) -> out [n, n] float64 with leading dimension ld >= n; rowsum [n]

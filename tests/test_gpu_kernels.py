@@ -551,12 +551,12 @@ GEMM_SHAPES = [  # (M, K1, K2, N)
 ]
 
 
-@pytest.fixture(params=["bf16x6", "fp32"])
+@pytest.fixture(params=["f16x3", "bf16x6", "fp32"])
 def projection_kind(request):
     from hgvae_amd import functional as Fn
     Fn.set_projection(request.param)
     yield request.param
-    Fn.set_projection("bf16x6")
+    Fn.set_projection(Fn.default_projection())
 
 
 @pytest.mark.parametrize("shape", GEMM_SHAPES)
@@ -589,7 +589,7 @@ def test_dual_linear_forward_backward(shape, projection_kind):
         assert float(base.detach()[:, n:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("kind", ["bf16x6", "fp32"])
+@pytest.mark.parametrize("kind", ["f16x3", "bf16x6", "fp32"])
 @pytest.mark.parametrize("shape", [(160_984, 138, 138, 138), (160_984, 105, 105, 138), (131_072 + 7, 138, None, 56),
                                    (70_001, 276, None, 138), (100_003, 256, 256, 256)])
 def test_projection_kernels_at_benchmark_rows(shape, kind):
@@ -617,7 +617,7 @@ def test_projection_kernels_at_benchmark_rows(shape, kind):
         img_t = Fn._image(w[:, :k1], None, True)
         assert img.kind == kind
     finally:
-        Fn.set_projection("bf16x6")
+        Fn.set_projection(Fn.default_projection())
     y = Fn._gemm_nt(xa, img, xb, bias, n)
     ref = xa.double() @ w[:, :k1].double().t() + bias.double()
     if k2:
@@ -646,7 +646,97 @@ def test_projection_kernels_at_benchmark_rows(shape, kind):
             Fn._gemm_tn2(g, xa, xb, True, both[:, :k1], both[:, k1:], bsum, accumulate=True)
             assert float((both.double() - 2 * refw2).abs().max()) <= 2 * tol
     finally:
-        Fn.set_projection("bf16x6")
+        Fn.set_projection(Fn.default_projection())
+
+
+def _scaled_cases():
+    """Operands that exercise the power-of-two scales of the f16x3 kernels (name, rows, maker of A, maker of G)."""
+    def randn(m, k, gen):
+        return torch.randn(m, k, device=dev(), generator=gen)
+
+    def chunks(sign):           # every 32-wide k chunk 300x larger (smaller) than the one before
+        def make(m, k, gen):
+            return randn(m, k, gen) * (300.0 ** (sign * torch.arange(k, device=dev()).div(32, rounding_mode="floor"))).float()
+        return make
+
+    def row_exp(m, span):       # the same exponent for a row in both sources of a product
+        return ((torch.arange(m, device=dev()) * 7919) % (2 * span) - span).float().unsqueeze(1)
+
+    def row_scaled(m, k, gen):  # rows between 1e-30 and 1e30
+        return randn(m, k, gen) * 10.0 ** row_exp(m, 30)
+
+    def one_hot(m, k, gen):     # sparse 0/1 rows, rows of zeros, rows of different magnitude
+        x = (torch.rand(m, k, device=dev(), generator=gen) < 0.02).float()
+        x[::7] = 0
+        return x * 10.0 ** row_exp(m, 20)
+
+    def growing(m, k, gen):     # later rows far larger than earlier ones
+        return randn(m, k, gen) * (10.0 ** (torch.arange(m, device=dev()).float() / m * 12 - 6)).unsqueeze(1)
+
+    def zeros_first(m, k, gen):
+        x = randn(m, k, gen)
+        x[: m // 3] = 0
+        return x
+
+    def col_scaled(m, k, gen):
+        return randn(m, k, gen) * (10.0 ** torch.randint(-6, 1, (1, k), device=dev(), generator=gen).float())
+
+    return [("rising chunks", 2048, chunks(1), randn), ("falling chunks", 2048, chunks(-1), randn),
+            ("rows 1e-30..1e30", 4099, row_scaled, randn), ("one-hot rows", 4096, one_hot, randn),
+            ("tiny", 4096, lambda m, k, gen: randn(m, k, gen) * 1e-12, lambda m, k, gen: randn(m, k, gen) * 1e-9),
+            ("growing rows", 20011, growing, growing), ("falling rows", 20011, lambda m, k, gen: growing(m, k, gen).flip(0), randn),
+            ("zero rows first", 20000, zeros_first, zeros_first), ("columns 1e-6..1", 20000, randn, col_scaled)]
+
+
+@pytest.mark.parametrize("tn_f16", [False, True])
+@pytest.mark.parametrize("case", _scaled_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("widths", [(138, 138, 138), (105, 0, 138), (256, 256, 256), (7, 0, 3)])
+def test_scaled_fp16_products_keep_fp32_accuracy(case, widths, tn_f16, monkeypatch):
+    """f16x3 scales every operand by a power of two before it is split into fp16 pieces: one scale per row of A (chosen
+    from the row's first k chunk and lowered when a later chunk would overflow) and one per weight row.  Operands with
+    rows or chunks of very different magnitude must still come out at fp32 accuracy: every output element within 1e-6 of
+    ITS OWN sum of |terms| (the two sources of a row share their magnitude here: a term whose operands both lie more than
+    2^16 below the largest entry of their rows keeps an absolute, not a relative, accuracy).  Weight gradients (2e-6 per element, 1e-6 of the largest sum for the matrix as a whole) run
+    on the three-piece bf16 kernel by default; the optional fp16 weight-gradient kernel (one scale per workgroup and
+    operand, lowered while the rows stream by) is held to the same bar on every case whose columns lie within its
+    stated range (2^16 below the largest entry of a 144-column group)."""
+    from hgvae_amd import functional as Fn
+    name, m, make_a, make_g = case
+    if tn_f16 and name in ("rising chunks", "falling chunks"):
+        pytest.skip("columns 300^8 apart: outside the stated range of the one-scale-per-workgroup kernel")
+    monkeypatch.setattr(Fn, "_tn_f16", tn_f16)
+    k1, k2, n = widths
+    gen = torch.Generator(device=dev()).manual_seed(7)
+    xa, xb = Fn.as_padded(make_a(m, k1, gen)), (Fn.as_padded(make_a(m, k2, gen)) if k2 else None)
+    wa = torch.randn(n, k1, device=dev(), generator=gen) * 0.1
+    wb = torch.randn(n, k2, device=dev(), generator=gen) * 0.1 if k2 else None
+    bias = torch.randn(n, device=dev(), generator=gen) * 0.01
+    g = Fn.as_padded(make_g(m, n, gen))
+    Fn.set_projection("f16x3")
+    try:
+        img = Fn._image(wa, wb, False)
+        assert img.kind == "f16x3"
+        y = Fn._gemm_nt(xa, img, xb, bias, n)
+        x_all = torch.cat([xa[:, :k1], xb[:, :k2]], 1) if k2 else xa[:, :k1]
+        w_all = torch.cat([wa, wb], 1) if k2 else wa
+        want = x_all.double() @ w_all.double().t() + bias.double()
+        terms = x_all.double().abs() @ w_all.double().abs().t() + bias.double().abs()
+        assert torch.isfinite(y).all()
+        assert float(((y[:, :n].double() - want).abs() / terms.clamp_min(1e-300)).max()) <= 1e-6
+        if k2:
+            ga, gb_, gbias = Fn._gemm_tn2(g, xa, xb, True)
+            gw = torch.cat([ga, gb_], 1)
+        else:
+            gw, gbias = Fn._gemm_tn(g, xa, True)
+        wantw = g[:, :n].double().t() @ x_all.double()
+        termsw = g[:, :n].double().abs().t() @ x_all.double().abs()
+        err = (gw.double() - wantw).abs()
+        assert float(err.max()) <= 1e-6 * float(termsw.max())
+        assert float((err / termsw.clamp_min(1e-300)).max()) <= 2e-6
+        wantb, termsb = g[:, :n].double().sum(0), g[:, :n].double().abs().sum(0)
+        assert float(((gbias.double() - wantb).abs() / termsb.clamp_min(1e-300)).max()) <= 2e-6
+    finally:
+        Fn.set_projection(Fn.default_projection())
 
 
 @pytest.mark.parametrize("m,n,k1,k2", [(1, 5, 3, 2), (4, 16, 16, 16), (5, 17, 33, 7), (37, 138, 138, 28), (1000, 56, 138, 138),

@@ -272,11 +272,16 @@ def _compare_step(ref, mod, loss_ref, loss, skip_grad=()):
 def test_attention_train_step_matches_oracle(sizes):
     from hgvae_amd.noise import NoiseTape, use_noise
     from hgvae_amd.vae import SkipconAttentionVAE, train_step_loss
-    gen = torch.Generator().manual_seed(10)
+    # Seed: with seed 10 one pre-activation of a later level of the ragged batch lies within 3e-7 of zero, so its relu
+    # mask - and with it a fixed 8e-3 of one bias gradient - is decided by the rounding of the first projection
+    # (measured: additive noise of 3e-7 on that projection's output flips it for one noise seed in four, under every
+    # projection arithmetic; the three arithmetics land on different sides).  Seeds 11-15 have no such element.
+    seed = 11
+    gen = torch.Generator().manual_seed(seed)
     ei, n, batch = path_batch(sizes)
     f_in, h, z, ns = 60, 256, 28, 10
     x = torch.randn(n, f_in, generator=gen)
-    torch.manual_seed(10)
+    torch.manual_seed(seed)
     ref = OM.SkipconAttentionVAE(f_in, h, z, ns)
     randomize_bn(ref, gen)
     ref.train()

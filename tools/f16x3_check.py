@@ -69,8 +69,68 @@ def timing(m, k1, k2, n, reps=30):
     print(f"time m={m} k={k1}+{k2} n={n}: " + "  ".join(f"{k} {v:.1f} us" for k, v in res.items()), flush=True)
 
 
+def tn_case(name, m, n, ka, kb, make_g, make_a, reps=20):
+    """Weight gradients G^T [Xa | Xb] and column sums of G: error over the largest sum of |terms| / per element, time."""
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    g = Fn.as_padded(make_g(m, n, gen))
+    xa = Fn.as_padded(make_a(m, ka, gen))
+    xb = Fn.as_padded(make_a(m, kb, gen)) if kb else None
+    x_all = torch.cat([xa[:, :ka], xb[:, :kb]], 1) if kb else xa[:, :ka]
+    want = g[:, :n].double().t() @ x_all.double()
+    terms = g[:, :n].double().abs().t() @ x_all.double().abs()
+    wb = g[:, :n].double().sum(0)
+    tb = g[:, :n].double().abs().sum(0)
+    out = {}
+    for kind in ("bf16x6", "f16x3"):
+        Fn.set_projection(kind)
+        run = (lambda: Fn._gemm_tn2(g, xa, xb, True)) if kb else (lambda: Fn._gemm_tn(g, xa, True))
+        res = run()
+        gw = torch.cat([res[0], res[1]], 1) if kb else res[0]
+        gb = res[-1]
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        d = (gw.double() - want).abs()
+        out[kind] = (float(d.max() / terms.max()), float((d / terms.clamp_min(1e-300)).max()),
+                     float(((gb.double() - wb).abs() / tb.clamp_min(1e-300)).max()), e0.elapsed_time(e1) / reps * 1e3)
+    print(f"tn {name:30s} m={m} n={n} k={ka}+{kb}: " + "  ".join(
+        f"{k} {v[0]:.2e} (per element {v[1]:.2e}, bias {v[2]:.2e}) {v[3]:.1f} us" for k, v in out.items()), flush=True)
+
+
+def tn_main():
+    randn = lambda m, k, g: torch.randn(m, k, device=DEV, generator=g)
+    tn_case("normal", 160984, 138, 138, 138, randn, randn)
+    tn_case("normal single", 160984, 138, 138, 0, randn, randn)
+    tn_case("gradient-sized G", 160984, 138, 138, 138, lambda m, k, g: randn(m, k, g) * 1e-9, randn)
+    tn_case("ragged rows", 40001, 138, 105, 0, randn, randn)
+
+    def col_scaled(m, k, g):     # columns of very different magnitude
+        return randn(m, k, g) * (10.0 ** torch.randint(-6, 1, (1, k), device=DEV, generator=g).float())
+    tn_case("columns 1e-6 .. 1", 160984, 138, 138, 138, col_scaled, randn)
+
+    def growing(m, k, g):        # later rows far larger: the running scale is lowered again and again
+        return randn(m, k, g) * (10.0 ** (torch.arange(m, device=DEV).float() / m * 12 - 6)).unsqueeze(1)
+    tn_case("rows growing 1e-6 .. 1e6", 160984, 138, 138, 138, growing, growing)
+    tn_case("rows falling", 160984, 138, 138, 138, lambda m, k, g: growing(m, k, g).flip(0), randn)
+
+    def blocky(m, k, g):         # zeros first, then data
+        x = randn(m, k, g)
+        x[: m // 3] = 0
+        return x
+    tn_case("zero rows first", 160984, 138, 138, 138, blocky, blocky)
+    tn_case("batch 256", 1285158, 138, 138, 138, randn, randn, reps=5)
+
+
 def main():
     randn = lambda m, k, g: torch.randn(m, k, device=DEV, generator=g)
+    if "--tn" in sys.argv:
+        return tn_main()
     if "--time-only" in sys.argv:
         for shape in ((160984, 138, 138, 138), (160984, 138, 0, 138), (160984, 105, 0, 138), (1285158, 138, 138, 138)):
             timing(*shape)
