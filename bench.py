@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
 L2_GATHER_GBS = 17800.0        # row gather served by an XCD's L2: 16.8-18.8 TB/s measured chip-wide
-BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA peak; an fp32-accurate product costs six bf16 products
+BF16_DENSE_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA peak; an fp32-accurate product costs three fp16 piece products (f16x3,
+                               # the default of the NT products) or six bf16 ones (bf16x6: the weight gradients)
 FP32_MFMA_TFLOPS = 157.0
 
 WORKLOADS = {
@@ -344,6 +345,10 @@ def main():
                                     "gathered_GBps": round(rate(aggw, lambda n, f, e: agg_gather_bytes(n, f, e) + 4 * e), 1),
                                     "compulsory_GBps": round(rate(aggw, lambda n, f, e: agg_compulsory_bytes(n, f, e) + 4 * e), 1)}
             proj = {}
+            kind_now = Fn.default_projection()
+            tn_kind = "f16x3" if (kind_now == "f16x3" and Fn._tn_f16) else ("bf16x6" if kind_now in ("f16x3", "bf16x6") else "fp32")
+            arith = {"nt": kind_now, "tn": tn_kind}
+            pieces = {k: {"f16x3": 3, "bf16x6": 6, "fp32": 16}[v] for k, v in arith.items()}     # fp32 MFMA: 1/16 of the 16-bit rate
             for kname, label in (("nt", "C[M,N] = A[M,K] W^T (forward and grad-input products)"),
                                  ("tn", "GW[N,K] = G^T A (weight gradients, reduction included)")):
                 items = [(sh, ms) for (k, sh, ms) in recs if k == kname]
@@ -355,7 +360,8 @@ def main():
                 ent = {"what": label, "launches_per_step": len(items) // probe_steps,
                        "ms_per_step": round(ms / probe_steps, 3),
                        "tflops_fp32_equiv": round(flops / (ms * 1e-3) / 1e12, 1),
-                       "frac_of_bf16x6_peak": round(flops / (ms * 1e-3) / 1e12 / (BF16_DENSE_TFLOPS / 6), 4),
+                       "arithmetic": arith[kname], "piece_products": pieces[kname],
+                       "frac_of_split_peak": round(flops / (ms * 1e-3) / 1e12 / (BF16_DENSE_TFLOPS / pieces[kname]), 4),
                        "operand_GBps": round(operand / (ms * 1e-3) / 1e9, 1),
                        "operand_frac_of_hbm_peak": round(operand / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 if pmc and kname in pmc.get("projections", {}):
