@@ -117,6 +117,22 @@ class GraphShard:
     def __len__(self) -> int:
         return len(self._node_ptr_host) - 1
 
+    @property
+    def uniform(self) -> bool:
+        """True when every graph of the shard has the same nodes and edges (frames of one molecule): then all batches
+        of one size share their ``edge_index`` / ``batch`` vector and carry a ``structure_id`` (see
+        :class:`hgvae_amd.graphed.CapturedTraining`).  Decided once, with one read-back."""
+        u = getattr(self, "_uniform", None)
+        if u is None:
+            sizes, ecnt = np.diff(self._node_ptr_host), np.diff(self._edge_ptr_host)
+            u = len(sizes) > 0 and bool((sizes == sizes[0]).all()) and bool((ecnt == ecnt[0]).all())
+            if u and ecnt[0] > 0:
+                g, e = len(sizes), int(ecnt[0])
+                local = self.edge_index.view(2, g, e) - self.node_ptr[:-1].view(1, g, 1)
+                u = bool((local == local[:, :1, :]).all().item())
+            self._uniform = u
+        return u
+
     def batch(self, ids: Sequence[int], with_csr: bool = True) -> Batch:
         """The graphs ``ids`` (any order) as one Batch: ``x`` (padded layout), ``edge_index``, ``batch``,
         ``ptr``, ``edge_attr`` and, with ``with_csr``, ``graph`` - the batch's :class:`Graph` with both CSR
@@ -161,6 +177,8 @@ class GraphShard:
         out = Batch(x=x, edge_index=ei, edge_attr=ea, batch=bvec)
         out.ptr = d_nptr
         out.num_graphs = b
+        if self.uniform:
+            out.structure_id = ("uniform", id(self), b)
         if with_csr:
             out.graph = Graph.from_parts(ei, n_out, _Csr(rp_d, col_d, perm_d), _Csr(rp_s, col_s, perm_s))
         return out

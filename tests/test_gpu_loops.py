@@ -374,3 +374,80 @@ def test_evaluation_mode_stays_differentiable():
         assert float((p.grad.double().cpu() - r).abs().max()) <= 1e-4 * max(float(r.abs().max()), 1e-6), name
     for name, b in mod.named_buffers():                      # evaluation leaves the statistics alone
         assert torch.equal(b, before[name]), name
+
+
+def _frames(n_batches, graphs, nodes, f, seed):
+    """Batches of `graphs` path graphs of `nodes` nodes each: one topology, new features per batch (MD frames)."""
+    from hgvae_amd.data import Batch
+    gen = torch.Generator().manual_seed(seed)
+    ei, n, bvec = path_batch([nodes] * graphs)
+    dev = torch.device("cuda:0")
+    eid, bd = ei.to(dev), bvec.to(dev)
+    return [Batch(x=torch.randn(n, f, generator=gen).to(dev), edge_index=eid.clone(), batch=bd.clone()) for _ in range(n_batches)]
+
+
+def test_captured_training_replays_one_capture_on_new_features():
+    """Batches that share (edge_index, batch) are served by ONE captured step whose input is overwritten: with a frozen
+    optimizer, the loss of batch k through CapturedTraining is bit-identical to a step captured directly on batch k and
+    replayed from the same noise counter."""
+    from hgvae_amd.graphed import CapturedTraining, GraphedTrainStep
+    from hgvae_amd.graph import new_padded
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    batches = _frames(4, 6, 23, 10, seed=60)          # 10 features: the captured input lives in the padded layout (ld 12)
+    torch.manual_seed(60)
+    model = SkipconVAE(10, 32, 4).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.0, capturable=True)
+    cap = CapturedTraining(model, opt, seed=11)
+    cap.step(batches[0])
+    assert len(cap._entries) == 1 and cap.captured_steps == 1
+    entry = cap._entries[0][3]
+    for data in batches[1:]:
+        counter = entry.counter.clone()
+        got = cap.step(data).clone()
+        assert len(cap._entries) == 1                   # recognised by comparing edge_index / batch on the device
+        x = new_padded(data.x.size(0), data.x.size(1), dev)
+        x.copy_(data.x)
+        ref = GraphedTrainStep(model, opt, x, data.edge_index, data.batch, seed=11)
+        ref.counter.copy_(counter)
+        assert torch.equal(ref(), got)
+    assert cap.captured_steps == 4 and cap.eager_steps == 0
+
+
+def test_captured_training_epochs_learn_and_fall_back():
+    """Epochs over a device-resident data set of equal graphs: the shard tags its batches with a structure id, the full
+    batches and the smaller last one get one capture each, the loss falls; a data set of unequal graphs runs eagerly
+    once the capture budget is used up, with the same optimizer."""
+    from hgvae_amd.data import Data
+    from hgvae_amd.graphed import CapturedTraining
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.shard import GraphShard
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(61)
+    ei, _, _ = path_batch([30])
+    base = torch.randn(30, 12, generator=gen)
+    frames = [Data(x=base + 0.1 * torch.randn(30, 12, generator=gen), edge_index=ei.clone()) for _ in range(22)]
+    shard = GraphShard.from_data_list(frames, dev)
+    assert shard.uniform
+    loader = shard.loader(8)                              # 8 + 8 + 6 graphs
+    assert next(iter(loader)).structure_id == ("uniform", id(shard), 8)
+    torch.manual_seed(61)
+    model = SkipconVAE(12, 32, 4).to(dev).train()
+    opt = FlatAdam(model.parameters(), lr=1e-2, capturable=True)
+    cap = CapturedTraining(model, opt, seed=5)
+    losses = [cap.train_epoch(loader) for _ in range(25)]
+    assert all(v == v for v in losses)
+    assert len(cap._entries) == 2 and cap.eager_steps == 0 and cap.captured_steps == 75
+    assert sorted(losses[-5:])[2] < sorted(losses[:5])[2]
+    assert int(model.encoder1[2].num_batches_tracked) == 150        # two encode passes per step
+    # unequal graphs: no structure id, every batch differs; two captures allowed, the rest eager
+    ragged = [Data(x=torch.randn(n, 12, generator=gen), edge_index=path_batch([n])[0]) for n in (5, 9, 14, 20, 27, 33)]
+    rshard = GraphShard.from_data_list(ragged, dev)
+    assert not rshard.uniform
+    assert not hasattr(next(iter(rshard.loader(2))), "structure_id")
+    cap2 = CapturedTraining(model, opt, seed=6, max_structures=2)
+    w0 = model.encoder1[0].lin_l.weight.detach().clone()
+    v = cap2.train_epoch(rshard.loader(2))
+    assert v == v and cap2.captured_steps == 2 and cap2.eager_steps == 1
+    assert not torch.equal(model.encoder1[0].lin_l.weight.detach(), w0)

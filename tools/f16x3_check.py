@@ -83,6 +83,7 @@ def tn_case(name, m, n, ka, kb, make_g, make_a, reps=20):
     out = {}
     for kind in ("bf16x6", "f16x3"):
         Fn.set_projection(kind)
+        Fn._tn_f16 = kind == "f16x3"          # the fp16 weight-gradient kernel is opt-in (HGVAE_TN_F16=1)
         run = (lambda: Fn._gemm_tn2(g, xa, xb, True)) if kb else (lambda: Fn._gemm_tn(g, xa, True))
         res = run()
         gw = torch.cat([res[0], res[1]], 1) if kb else res[0]
