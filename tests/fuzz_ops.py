@@ -432,6 +432,34 @@ def fuzz_model(rng, gen):
     dev_l, cpu_l = abs(float(loss.detach()) - float(loss_ref.detach())) / lscale, abs(float(loss32.detach()) - float(loss_ref.detach())) / lscale
     # bars: loss 1e-5, gradients 2e-4 (reported on the gradient scale, hence the factor 20), each widened to 4x the fp32 CPU error
     errs = {"loss": 20 * dev_l / max(1.0, 4 * cpu_l / 1e-5), "grad": dev_err / max(1.0, 4 * cpu_err / 2e-4)}
+    if errs["grad"] > 2e-4:
+        # Before calling it a failure: is the case decided by roundings?  Narrow levels over a few hundred rows, next to
+        # one- and two-node graphs, can hold a batch-norm column that is almost constant (1 / std up to 316) in front of a
+        # relu: a perturbation of a few fp32 ulps then flips one mask bit and moves some gradient by a fixed 1e-3 .. 1e-2,
+        # under every arithmetic (measured: additive noise of 3e-7 on the first projection's output reproduces the exact
+        # same error for two noise seeds out of four).  The float64 restatement itself is asked: its gradients on inputs
+        # perturbed by 2e-7 (relative) - if THEY move by more than the bar, no fp32 path can be held to it; the bar then
+        # follows 4x that movement, as it follows the fp32 CPU restatement's own error.
+        cond = 0.0
+        for _ in range(4):
+            refp = make().double()
+            refp.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in state.items()})
+            refp.train()
+            for name, prm in refp.named_parameters():
+                if name in frozen:
+                    prm.requires_grad_(False)
+            xp = x.double() * (1 + 2e-7 * torch.randn(x.shape, generator=cpu_gen).double())
+            if want_gx:
+                xp.requires_grad_(True)
+            ref_loss(refp, xp, O.NoiseTape(tape64)).backward()
+            for name, prm in refp.named_parameters():
+                if rp[name].grad is not None:
+                    r = rp[name].grad.double()
+                    cond = max(cond, float((prm.grad.double() - r).abs().max()) / max(float(r.abs().max()), floor))
+            if want_gx:
+                cond = max(cond, float((xp.grad - x64.grad).abs().max()) / max(float(x64.grad.abs().max()), floor))
+        errs["grad"] = dev_err / max(1.0, 4 * cpu_err / 2e-4, 4 * cond / 2e-4)
+        errs["fragile_cases"] = 0.0 if cond <= 2e-4 else 1e-300        # shows up in the worst-error summary when it happened
     if os.environ.get("FUZZ_MODEL_DETAIL"):
         print(f"  model detail: {kind} loss f64 {float(loss_ref.detach()):.9g}; rel dev {dev_l:.2e} cpu32 {cpu_l:.2e}; "
               f"grad dev {dev_err:.2e} cpu32 {cpu_err:.2e}; h={h} n={n} e={e}", flush=True)
