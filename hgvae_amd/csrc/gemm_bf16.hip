@@ -1030,6 +1030,9 @@ __device__ __forceinline__ void tn16h_body(const Tn16Args& a, unsigned char* lds
         }
         if (t == 0) { slot[2 * (int)(s % 3)] = 0u; slot[2 * (int)(s % 3) + 1] = 0u; }      // read a step ago, published again two steps on
         load_step(min(s + 3, s_hi - 1), PAR ^ 1);          // unconditional (past the end: the last tile again), so that waits stay counted
+        // largest values of the tile after next, in front of the products: the LDS atomics then have the whole product
+        // phase to finish before the barrier
+        if (s + 2 < s_hi) publish(s + 2, PAR);
         // three piece products, small terms first: gl*xh, gh*xl, gh*xh
 #define HGV_TNH_TERM(GP, XP)                                                                            \
         _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                   \
@@ -1055,7 +1058,6 @@ __device__ __forceinline__ void tn16h_body(const Tn16Args& a, unsigned char* lds
                 for (int r = 0; r < 4; ++r) accb[i][r] *= rg;
             }
         }
-        if (s + 2 < s_hi) publish(s + 2, PAR);
         if (pace) {
             const int done = (int)(s - s_lo) + 1;
             if (lane == 0) __hip_atomic_store(pace_mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
