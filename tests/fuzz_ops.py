@@ -205,8 +205,16 @@ def fuzz_gat(rng, gen):
     # zero wherever the leaky slope is the same along the row: both attention vectors are measured on their common scale
     att_scale = max(float(ref["att_src"].grad.abs().max()), float(ref["att_dst"].grad.abs().max()), 1e-6)
     pairs = [("gx", xd.grad, xr.grad, x32.grad, max(float(xr.grad.abs().max()), 1e-6))]
+    # the projection's weight gradient is x^T (gradient of the projected features): on the scale of the sum of its |terms|
+    # (a 1 x 1 layer over a few hundred nodes is one sum that may cancel)
+    xw = (x.double() @ ref["lin_src.weight"].detach().t()).requires_grad_(True)
+    O.dense_gat(xw, ei, torch.eye(c, dtype=torch.float64), ref["att_src"].detach(), ref["att_dst"].detach(),
+                ref["bias"].detach()).backward(go.double())
+    lin_terms = float((xw.grad.abs().t() @ x.double().abs()).max())
     for k, v in conv.named_parameters():
         scale = att_scale if k.startswith("att_") else max(float(ref[k].grad.abs().max()), 1e-6)
+        if k == "lin_src.weight":
+            scale = max(scale, lin_terms)
         pairs.append(("g_" + k.split(".")[0], v.grad, ref[k].grad, ref32[k].grad, scale))
     raw = {}
     for name, got, r64, r32, scale in pairs:
@@ -281,6 +289,7 @@ def fuzz_losses(rng, gen):
     mean, ls = m64[:, :z], m64[:, z:]
     z64 = (mean.unsqueeze(0) + ls.exp().unsqueeze(0) * eps.double()).mean(0)
     kl64 = (-0.5 * torch.sum(1 + 2 * ls - mean.pow(2) - ls.exp().pow(2), dim=-1)).mean()
+    kl_terms = (0.5 * torch.sum(1 + 2 * ls.abs() + mean.pow(2) + ls.exp().pow(2), dim=-1)).mean().detach()
     (z64 * gz.double()).sum().backward(retain_graph=True)
     r_rep = m64.grad.clone(); m64.grad = None
     kl64.backward()
@@ -293,7 +302,9 @@ def fuzz_losses(rng, gen):
     mse64 = torch.nn.functional.mse_loss(a64, b.double())
     mse64.backward()
     errs = {"z": rel(zz, z64), "g_reparam": rel(g_rep, r_rep),
-            "kl": abs(float(kl.detach()) - float(kl64.detach())) / max(abs(float(kl64.detach())), 1e-30), "g_kl": rel(g_kl, r_kl),
+            # on the scale of the terms it sums (1 + 2 ls - mean^2 - exp(2 ls) cancels for small ls, mean: a one-element
+            # batch has no relative accuracy of its own)
+            "kl": abs(float(kl.detach()) - float(kl64.detach())) / max(float(kl_terms), 1e-30), "g_kl": rel(g_kl, r_kl),
             "mse": abs(float(mse.detach()) - float(mse64.detach())) / max(float(mse64.detach()), 1e-30), "g_mse": rel(a.grad, a64.grad)}
     return f"losses n={n} z={z} ns={ns} spread={spread}", errs, 2e-6
 
