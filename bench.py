@@ -208,7 +208,18 @@ def main():
     from hgvae_amd.distributed import FlatGradBucket, all_reduce_any, barrier, init_from_env
     from hgvae_amd.graph import graph_of
 
-    rank, world, local_rank = init_from_env()
+    # stdout carries the one JSON line: whatever a backend prints while it connects (gloo does, from C++) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        rank, world, local_rank = init_from_env()
+        if world > 1:
+            barrier()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     device = torch.device("cuda", local_rank)
