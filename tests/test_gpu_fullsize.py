@@ -183,3 +183,27 @@ def test_train_step_runs_and_is_reproducible_at_full_size(big):
         want = ((recon.double() - xin.double()) ** 2).mean() + \
             (-0.5 * (1 + 2 * log_std.double() - mean.double() ** 2 - torch.exp(log_std.double()) ** 2).sum(-1)).mean()
     assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want))
+
+
+def test_paced_two_part_product_at_hidden_width_256():
+    """A 256 -> 256 projection keeps its weight image in LDS as two parts along N; from 256 MB of A upwards the two parts
+    are walked in step by paired workgroups (the second reader of a row finds it in L2).  Rows must not depend on who
+    ran ahead: two launches agree bit for bit, slices computed on their own equal the full result, and sampled rows match
+    a float64 product."""
+    from hgvae_amd import functional as Fn
+    m, h = 300_000, 256
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(m, h, device=DEV, generator=gen)
+    w = torch.randn(h, h, device=DEV, generator=gen) * 0.1
+    bias = torch.randn(h, device=DEV, generator=gen)
+    with torch.no_grad():
+        full = Fn.dual_linear(x, w, None, None, bias)
+        assert torch.equal(full, Fn.dual_linear(x, w, None, None, bias))
+        for lo, hi in ((0, 4100), (m // 2 - 11, m // 2 + 2049), (m - 1000, m)):
+            assert torch.equal(Fn.dual_linear(x[lo:hi].contiguous(), w, None, None, bias), full[lo:hi])
+    rows = torch.cat([torch.arange(0, 2048, device=DEV), torch.randint(0, m, (4096,), device=DEV, generator=gen),
+                      torch.arange(m - 2048, m, device=DEV)])
+    want = x.double()[rows] @ w.double().t() + bias.double()
+    assert rel(full[rows], want) <= 2e-6
+    del full, x
+    torch.cuda.empty_cache()
