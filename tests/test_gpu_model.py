@@ -540,6 +540,8 @@ def test_planned_weight_images_follow_every_parameter_change():
     from hgvae_amd import functional as Fn
     from hgvae_amd import synthetic
     from hgvae_amd.vae import SkipconVAE, train_step_loss
+    if Fn.default_projection() == "fp32":
+        pytest.skip("HGVAE_PROJECTION=fp32: the fp32 kernels pack their images per use, there is no plan")
     dev = torch.device("cuda:0")
     batch = synthetic.path_graph_batch([138] * 4, 60, seed=3, device=dev)
 
