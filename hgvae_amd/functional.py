@@ -458,15 +458,22 @@ _branch_updates: list = []      # (BatchNorm module, [2, H] stand-in holding mom
 def apply_branch_updates() -> None:
     """Running-statistics updates that the branch deferred; call on the trunk stream after the branch has joined."""
     import numpy as np
+    bufs, keeps, adds, counters = [], [], [], []
     for bn, stand_in, momentum in _branch_updates:
         keep = float(np.float32(1.0) - np.float32(momentum))          # the kernel's (1.f - momentum)
-        with torch.no_grad():
-            if bn.running_mean is not None:
-                bn.running_mean.mul_(keep).add_(stand_in[0])
-            if bn.running_var is not None:
-                bn.running_var.mul_(keep).add_(stand_in[1])
-            if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+        if bn.running_mean is not None:
+            bufs.append(bn.running_mean); keeps.append(keep); adds.append(stand_in[0])
+        if bn.running_var is not None:
+            bufs.append(bn.running_var); keeps.append(keep); adds.append(stand_in[1])
+        if bn.num_batches_tracked is not None:
+            counters.append(bn.num_batches_tracked)
+    with torch.no_grad():
+        # all levels in three launches (the same multiply, then add, per buffer as one level at a time would do)
+        if bufs:
+            torch._foreach_mul_(bufs, keeps)
+            torch._foreach_add_(bufs, adds)
+        if counters:
+            torch._foreach_add_(counters, 1)
     _branch_updates.clear()
 
 
