@@ -352,7 +352,7 @@ def custom_pool_step_loss(model, x, edge_index, batch):
         with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
             reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
         recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
-    return recon_loss + model.beta * model.kl_divergence(mean, log_std)
+    return torch.add(recon_loss, model.kl_divergence(mean, log_std), alpha=float(model.beta))
 
 
 def _to_device(data, device):
@@ -446,7 +446,8 @@ def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     mean, log_std = enc[-2], enc[-1]
     recon_loss = Fn.mse_loss(out[0], padded_input(x))
     kl_loss = model.kl_divergence(mean, log_std)
-    return recon_loss + lambda_kl * kl_loss
+    # one launch forward, and none backward for lambda = 1 (a separate product would cost one each way)
+    return torch.add(recon_loss, kl_loss, alpha=float(lambda_kl))
 
 
 def validate_vae(model, loader):
