@@ -387,10 +387,28 @@ def _image(wa: torch.Tensor, wb: Optional[torch.Tensor], transposed: bool) -> _I
     return _images((wa, wb, transposed))[0]
 
 
+# HGVAE_CHECK_PADS=1: every projection checks (with a host synchronisation) that the pad columns [K, ld) of its operands are
+# zero.  The f16x3 kernels take the largest entry of a row over the whole 16-byte chunks they load, so a stray value in a pad
+# column would set the row's scale; every buffer this package produces keeps its pads zero, and this switch proves it on a
+# given workload.
+_CHECK_PADS = os.environ.get("HGVAE_CHECK_PADS", "0") == "1"
+
+
+def _assert_zero_pads(*operands) -> None:
+    for t in operands:
+        if t is None or ld_of(t) <= t.size(1):
+            continue
+        pads = t.as_strided((t.size(0), ld_of(t) - t.size(1)), (t.stride(0), 1), t.storage_offset() + t.size(1))
+        if t.size(0) and float(pads.abs().max()) != 0.0:
+            raise _lib.HgvError(f"projection operand of shape {tuple(t.shape)} (leading dimension {ld_of(t)}) has non-zero pad columns")
+
+
 def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
     xa / xb must already be in the padded layout."""
     m = xa.size(0)
+    if _CHECK_PADS:
+        _assert_zero_pads(xa, xb)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     if ev:
