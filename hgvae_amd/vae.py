@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import functional as Fn
-from .graph import Graph, as_padded, graph_of
+from .graph import Graph, as_padded, graph_of, ld_of, new_padded, pad4
 from .data import Data
 from .nn import GATConv, GCNConv, GraphConv, SAGEConv, SAGPooling
 
@@ -34,6 +34,11 @@ def padded_input(x: torch.Tensor) -> torch.Tensor:
     if hit is not None and hit[0]() is x and hit[1] == x._version:
         return hit[2]
     p = as_padded(x)
+    if p is x and x.dim() == 2 and ld_of(x) > pad4(x.size(1)):
+        # a column slice of a wider matrix: the kernels load whole 16-byte chunks, and what lies behind the last column
+        # here is foreign data (it would meet zero weights, but it takes part in the row scale of the fp16 projections)
+        p = new_padded(x.size(0), x.size(1), x.device)
+        p.copy_(x)
     if p is not x:
         _pad_cache[key] = (weakref.ref(x, lambda _r, k=key: _pad_cache.pop(k, None)), x._version, p)
     return p

@@ -156,3 +156,26 @@ def test_graph_without_hubs_learns_that_the_long_pass_is_not_needed():
     torch.cuda.synchronize()
     assert not g.by_dst.long_rows(n).maybe_any()
     assert torch.equal(Fn.aggregate(x, g, mean=True), first)
+
+
+def test_input_that_is_a_column_slice_of_a_wider_matrix():
+    """x = wide[:, :F] is 16-byte aligned with a leading dimension far beyond F: what lies behind column F is foreign data,
+    here 1e30.  It must neither reach the result nor set the row scale of the fp16 projections: the forward pass equals the
+    one on a contiguous copy bit for bit."""
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(12)
+    n, f = 300, 10
+    wide = torch.randn(n, 32, device=dev, generator=gen)
+    wide[:, f:] = 1e30
+    x = wide[:, :f]
+    a = torch.arange(n - 1, device=dev)
+    ei = torch.cat([torch.stack([a, a + 1]), torch.stack([a + 1, a])], 1)
+    torch.manual_seed(12)
+    model = SkipconVAE(f, 32, 4).to(dev).eval()
+    with torch.no_grad():
+        got = model.encode(x, ei)
+        want = model.encode(x.contiguous(), ei)
+    for g, w in zip(got, want):
+        assert torch.isfinite(g).all()
+        assert torch.equal(g, w)
