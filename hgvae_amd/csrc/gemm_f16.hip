@@ -204,12 +204,15 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)part * img);
         f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
         const int npieces = (int)(img / 16);
-        for (int e0 = t; e0 < npieces; e0 += 8 * blockDim.x) {
-            f32x4 v[8];
+        // batches of 16 loads in flight per thread: with four waves (a few hundred row tiles in all) the 159 KB image is
+        // 39 loads per thread, and every batch pays the L2 latency once
+        constexpr int CB = 16;
+        for (int e0 = t; e0 < npieces; e0 += CB * blockDim.x) {
+            f32x4 v[CB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[min(e0 + u * (int)blockDim.x, npieces - 1)];
+            for (int u = 0; u < CB; ++u) v[u] = src[min(e0 + u * (int)blockDim.x, npieces - 1)];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < CB; ++u)
                 if (e0 + u * (int)blockDim.x < npieces) dst[e0 + u * (int)blockDim.x] = v[u];
         }
         for (int e = t; e < g.chunks * 4; e += blockDim.x) {
