@@ -99,6 +99,39 @@ class GraphedTrainStep:
         return self.loss
 
 
+class GraphedEvalStep:
+    """Captured evaluation of the loss on a fixed batch structure (``validate_vae``'s body, gvae/gvae_skipcon.py:190-204:
+    eval mode, no gradients, forward + second encode + recon + kl); fresh eps per replay through the device-side counter."""
+
+    def __init__(self, model: torch.nn.Module, x: torch.Tensor, edge_index: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                 lambda_kl: float = 1.0, loss_fn: Callable = train_step_loss, seed: int = 0, warmup: int = 2):
+        self.model, self.x, self.edge_index, self.batch, self.lambda_kl, self.loss_fn = model, x, edge_index, batch, lambda_kl, loss_fn
+        dev = x.device
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.noise = PhiloxNoise(seed, device_counter=self.counter)
+        graph_of(edge_index, x.size(0))
+        self.graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss = self._body()
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        self.noise.advance()
+        with torch.no_grad(), use_noise(self.noise):
+            return self.loss_fn(self.model, self.x, self.edge_index, self.batch, self.lambda_kl).detach()
+
+    def __call__(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss
+
+
 class CapturedTraining:
     """``train_vae`` for loaders whose batches repeat a structure, replayed as captured steps.
 
@@ -122,13 +155,14 @@ class CapturedTraining:
         self.model, self.optimizer, self.lambda_kl, self.loss_fn = model, optimizer, lambda_kl, loss_fn
         self.max_structures, self.seed = max_structures, seed
         self._entries: list = []            # (structure_id or None, edge_index, batch, GraphedTrainStep)
+        self._eval_entries: list = []       # the same for evaluation steps (GraphedEvalStep)
         self._bucket = getattr(optimizer, "bucket", None)
         self.captured_steps = self.eager_steps = 0
 
-    def _find(self, data):
+    def _find(self, data, entries=None):
         sid = getattr(data, "structure_id", None)
         shape = (tuple(data.x.shape), tuple(data.edge_index.shape))
-        for ent in self._entries:
+        for ent in (self._entries if entries is None else entries):
             esid, ei, bt, step = ent
             if (tuple(step.x.shape), tuple(ei.shape)) != shape:
                 continue
@@ -181,5 +215,35 @@ class CapturedTraining:
         for data in loader:
             data = _to_device(data, dev)
             total += self.step(data)
+            n += 1
+        return float(total.item()) / max(n, 1)
+
+    def validate_epoch(self, loader, lambda_kl: float = 1.0) -> float:
+        """Same contract as :func:`hgvae_amd.vae.validate_vae` (eval mode, no gradients, mean of recon + kl over the
+        batches), with batches of a known structure replayed as captured evaluation steps.  The model is left in eval mode,
+        as the reference's function leaves it."""
+        from .graph import new_padded
+        from .vae import _to_device
+        self.model.eval()
+        dev = next(self.model.parameters()).device
+        total = torch.zeros((), dtype=torch.float64, device=dev)
+        n = 0
+        for data in loader:
+            data = _to_device(data, dev)
+            step = self._find(data, self._eval_entries)
+            if step is None and len(self._eval_entries) < self.max_structures:
+                x = new_padded(data.x.size(0), data.x.size(1), dev)
+                x.copy_(data.x)
+                ei = data.edge_index.clone()
+                bt = data.batch.clone() if data.batch is not None else None
+                step = GraphedEvalStep(self.model, x, ei, bt, lambda_kl, loss_fn=self.loss_fn,
+                                       seed=self.seed + 104729 * (len(self._eval_entries) + 1))
+                self._eval_entries.append((getattr(data, "structure_id", None), ei, bt, step))
+            if step is None:
+                with torch.no_grad():
+                    total += self.loss_fn(self.model, data.x, data.edge_index, data.batch, lambda_kl)
+            else:
+                step.x.copy_(data.x)
+                total += step()
             n += 1
         return float(total.item()) / max(n, 1)

@@ -451,3 +451,35 @@ def test_captured_training_epochs_learn_and_fall_back():
     v = cap2.train_epoch(rshard.loader(2))
     assert v == v and cap2.captured_steps == 2 and cap2.eager_steps == 1
     assert not torch.equal(model.encoder1[0].lin_l.weight.detach(), w0)
+
+
+def test_captured_validation_matches_validate_vae():
+    """CapturedTraining.validate_epoch replays a captured evaluation step per batch structure.  In eval mode the only noise
+    left is eps of the reparameterisation, which enters the loss through the decoder: with the same trained weights the
+    captured epoch must land where the eager validate_vae does (different eps streams: compared within the spread of two
+    eager runs), replay after replay, and follow the weights when they change."""
+    from hgvae_amd.graphed import CapturedTraining
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.vae import SkipconVAE, validate_vae
+    dev = torch.device("cuda:0")
+    batches = _frames(6, 8, 30, 12, seed=70)
+    torch.manual_seed(70)
+    model = SkipconVAE(12, 32, 4, 10).to(dev).train()
+    opt = FlatAdam(model.parameters(), lr=1e-2, capturable=True)
+    cap = CapturedTraining(model, opt, seed=9)
+    for _ in range(20):
+        cap.train_epoch(batches)
+    eager = [validate_vae(model, batches) for _ in range(4)]
+    captured = [cap.validate_epoch(batches) for _ in range(4)]
+    assert len(cap._eval_entries) == 1 and not model.training
+    spread = max(eager) - min(eager)
+    mid = sum(eager) / len(eager)
+    assert len(set(captured)) > 1                                     # fresh eps per replay
+    assert all(abs(v - mid) <= 3 * spread + 1e-3 * abs(mid) for v in captured), (eager, captured)
+    # the captured step reads the weights at replay time: more training moves the validation loss
+    model.train()
+    for _ in range(40):
+        cap.train_epoch(batches)
+    after = cap.validate_epoch(batches)
+    assert abs(after - validate_vae(model, batches)) <= 3 * spread + 1e-3 * abs(after) + 0.05 * abs(after)
+    assert after < mid

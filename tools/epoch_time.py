@@ -49,5 +49,31 @@ def main():
               + (f"; captures {len(cap._entries)}, captured steps {cap.captured_steps}, eager steps {cap.eager_steps}" if cap else ""), flush=True)
 
 
+def validation():
+    """The same data through validate_vae (eager) and CapturedTraining.validate_epoch."""
+    from hgvae_amd.vae import validate_vae
+    frames = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(0)
+    a = torch.arange(137)
+    ei = torch.cat([torch.stack([a, a + 1]), torch.stack([a + 1, a])], 1)
+    base = torch.randn(138, 60, generator=gen)
+    shard = GraphShard.from_data_list([Data(x=base + 0.1 * torch.randn(138, 60, generator=gen), edge_index=ei) for _ in range(frames)], dev)
+    loader = shard.loader(32, with_csr=False)
+    torch.manual_seed(0)
+    model = SkipconVAE(60, 138, 28).to(dev)
+    cap = CapturedTraining(model, FlatAdam(model.parameters(), lr=1e-3, capturable=True), seed=1)
+    for name, run in (("eager validate_vae", lambda: validate_vae(model, loader)), ("captured validate_epoch", lambda: cap.validate_epoch(loader))):
+        v = run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            v = run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        print(f"{name:24s}: {len(loader)} batches of 32 graphs, {dt * 1e3:7.1f} ms per epoch = {dt / len(loader) * 1e3:.3f} ms per batch; loss {v:.4f}", flush=True)
+
+
 if __name__ == "__main__":
     main()
+    validation()
