@@ -5,8 +5,11 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", [11, 12])
-def test_random_shapes_against_float64(seed):
+# (seed, cases): seed 5 reaches a whole-step case that roundings decide (case 312: the harness asks the float64 restatement
+# how far its own gradients move under a 2e-7 input perturbation), seed 11 a 1 x 1 attention layer whose weight gradient is one
+# cancelling sum (case 320), seed 15 the KL of a one-element batch (case 54)
+@pytest.mark.parametrize("seed,cases", [(11, 330), (12, 250), (5, 320), (15, 80)])
+def test_random_shapes_against_float64(seed, cases):
     import fuzz_ops
-    fail, _ = fuzz_ops.run(250, seed)
+    fail, _ = fuzz_ops.run(cases, seed)
     assert fail is None, fail
