@@ -55,6 +55,17 @@ WORKLOADS = {
                     "GCNConv-scored pooling, re-decoded loss, beta 0.5", "weak"),
 }
 GRAPHS2_SIZES = [454, 2627, 4697, 11213, 11455, 11940, 13239, 15200]
+OTHER_WORKLOADS = ["chig32", "attention", "pool", "custom_pool", "large", "protein32"]     # timed after the headline (N = 1)
+CAPTURED_TOO = {"chig32", "attention", "pool", "custom_pool"}                            # a few thousand nodes: also as a HIP graph
+DTYPE_NOTE = {
+    "f16x3": "f32 (storage and accumulation fp32; projections emulate fp32 on the 16-bit matrix cores: forward / grad-input "
+             "products from two scaled fp16 pieces per operand and three piece products (f16x3, 22 operand bits), weight "
+             "gradients from three bf16 pieces and six products (bf16x6, 24 bits); fp32_mfma_ms_per_step is the same step on "
+             "v_mfma_f32_16x16x4_f32)",
+    "bf16x6": "f32 (storage and accumulation fp32; projections from three bf16 pieces per operand and six piece products on "
+              "the bf16 matrix cores, 24 operand bits)",
+    "fp32": "f32 (projections on v_mfma_f32_16x16x4_f32)",
+}
 
 
 def agg_gather_bytes(n, f, e):
@@ -77,14 +88,38 @@ def agg_compulsory_bytes(n, f, e, ld=None):
     return 2 * 4 * ld * n + 4 * e + 4 * (n + 1)
 
 
+SOURCE_FILES = ["bench.py", "include/hgvae_hip.h", "hgvae_amd/csrc/*.hip", "hgvae_amd/csrc/*.h", "hgvae_amd/functional.py",
+                "hgvae_amd/vae.py", "hgvae_amd/nn.py", "hgvae_amd/graph.py", "hgvae_amd/synthetic.py", "hgvae_amd/noise.py",
+                "hgvae_amd/optim.py", "hgvae_amd/distributed.py"]
+
+
+def source_hash():
+    """SHA-1 over the sources that decide what one step launches and moves: the kernels, the operators and models above
+    them, the workload generator and this file.  A counter summary is only valid for the sources it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for pat in SOURCE_FILES:
+        for f in sorted(glob.glob(os.path.join(ROOT, pat))):
+            h.update(os.path.relpath(f, ROOT).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_pmc(workload, graphs):
-    """Counter summary of this workload written by tools/pmc_bench.sh (separate rocprofv3 --pmc passes); None if absent."""
+    """(counter summary of this workload written by tools/pmc_bench.py, why it was refused or None).  The summary comes
+    from separate rocprofv3 --pmc passes and is kept under profiles/; one measured on other sources than the present
+    ones (its ``source_hash`` differs) is refused, so a kernel change without a counter refresh cannot skew the line."""
     for name in (f"pmc_{workload}_b{graphs}.json", f"pmc_{workload}.json"):
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
             continue
-    return None
+        if doc.get("source_hash") != source_hash():
+            return None, f"profiles/{name} was measured on sources {doc.get('source_hash')} (now {source_hash()}): not used"
+        doc["file"] = f"profiles/{name}"
+        return doc, None
+    return None, "no counter summary for this workload under profiles/"
 
 
 def build_workload(name, rank, world, device):
@@ -92,9 +127,11 @@ def build_workload(name, rank, world, device):
     from hgvae_amd import synthetic
     seed = 1000 + rank
     if name in ("protein256", "protein32", "attention32"):
+        # graph g of the job is drawn from seed 1000 + g whatever the number of ranks: the union of the ranks' shards of
+        # protein256 is the same 256 graphs for every N (rank r holds the contiguous ids shard_range(256, r, N))
         from hgvae_amd.distributed import shard_range
-        graphs = len(shard_range(256, rank, world)) if name == "protein256" else 32
-        batch = synthetic.protein_like_batch(graphs, seed=seed, device=device)
+        ids = shard_range(256, rank, world) if name == "protein256" else range(32 * rank, 32 * rank + 32)
+        batch = synthetic.protein_like_batch_by_index(ids, base_seed=1000, device=device)
         return (batch, "attention", (105, 256, 28)) if name == "attention32" else (batch, "skipcon", (105, 138, 28))
     if name == "large":
         return synthetic.local_random_graph(100_000, 20, 128, seed=seed, device=device), "skipcon", (128, 128, 28)
@@ -175,6 +212,124 @@ def cpu_baseline(batch, kind, dims, sample_graphs, budget_s=10.0):
             "edge_messages_per_s": (sage * e + gat * (e + nn_)) * n / dt}
 
 
+def timed_steps(step, steps, warmup):
+    """ms per step of ``step()`` on this GPU alone (no collective): warm-up, synchronise, time, synchronise."""
+    import torch
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def secondary_workload(name, device, steps=5, warmup=2, captured=False):
+    """One of the other configurations, timed on this GPU after the headline run: eager train steps (and, for the
+    batches of a few thousand nodes, the same step replayed as a captured HIP graph)."""
+    import gc
+    import torch
+    import hgvae_amd
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import graph_of
+    from hgvae_amd.optim import FlatAdam
+    batch, kind, dims = build_workload(name, 0, 1, device)
+    torch.manual_seed(0)
+    hgvae_amd.manual_seed(1234)
+    model, loss_fn = make_model(kind, dims)
+    model = model.to(device).train()
+    opt = FlatAdam(model.parameters(), lr=1e-3, capturable=captured)
+    bucket = opt.bucket
+    graph_of(batch.edge_index, batch.x.size(0)).check()
+
+    def step():
+        bucket.zero()
+        loss = loss_fn(model, batch.x, batch.edge_index, batch.batch, 1.0)
+        with Fn.direct_weight_grads():
+            loss.backward()
+        opt.step()
+        return loss
+
+    ms = timed_steps(step, steps, warmup)
+    n_graphs = batch.num_graphs
+    out = {"name": name, "workload": WORKLOADS[name][0], "graphs": n_graphs, "nodes": batch.x.size(0),
+           "edges": batch.edge_index.size(1), "steps": steps, "warmup": warmup, "launch": "eager",
+           "ms_per_step": round(ms, 3), "value": round(n_graphs / (ms * 1e-3), 1), "unit": "graphs/s"}
+    if captured:
+        from hgvae_amd.graphed import GraphedTrainStep
+        g = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, loss_fn=loss_fn, bucket=bucket, seed=1234)
+        ms_g = timed_steps(g, 4 * steps, warmup)
+        out["captured_ms_per_step"] = round(ms_g, 3)
+        out["captured_value"] = round(n_graphs / (ms_g * 1e-3), 1)
+        del g
+    del model, opt, bucket, batch, step
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def csr_build_bytes(n, e):
+    """Bytes the radix-sort CSR build of one direction moves by its own model: int64 edge list in and (key, edge id)
+    pairs out (24 E), one read and one write of the 8-byte pairs per 8-bit digit of a node id, and the three int32
+    outputs (12 E)."""
+    passes = max(1, -(-max(n - 1, 1).bit_length() // 8))
+    return (passes * 8 + 24 + 12) * e, passes
+
+
+def fresh_batch_cost(batch, device, reps=3):
+    """What a NEW batch costs before the step can run, measured on the headline batch: the two CSR builds from the
+    batch's edge_index (the headline's timed region replays one batch, so they are outside it), and the alternative
+    for a device-resident data set - gathering the batch, CSR included, from a packed shard (no sort per batch)."""
+    import torch
+    from hgvae_amd.graph import Graph
+    from hgvae_amd.shard import GraphShard
+    ei, n = batch.edge_index, batch.x.size(0)
+    e = ei.size(1)
+
+    def build():
+        g = Graph(ei, n)
+        g.by_src
+        return g
+
+    build()
+    torch.cuda.synchronize()
+    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        build()
+    t.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(t) * 1e3 / reps
+    per_dir, passes = csr_build_bytes(n, e)
+    out = {"csr_build_us": round(us, 1), "csr_build_what": "both CSRs (by target, by source) from int64 edge_index, "
+           f"{passes} radix passes of 8 bits each", "csr_build_bytes": 2 * per_dir,
+           "csr_build_GBps": round(2 * per_dir / (us * 1e-6) / 1e9, 1),
+           "csr_build_frac_of_hbm_peak": round(2 * per_dir / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    ptr = batch.ptr.to(device)
+    gid = torch.bucketize(ei[0], ptr[1:], right=True)
+    eptr = torch.zeros(ptr.numel(), dtype=torch.int64, device=device)
+    eptr[1:] = torch.cumsum(torch.bincount(gid, minlength=ptr.numel() - 1), 0)
+    shard = GraphShard(batch.x, ei, ptr.cpu(), eptr.cpu())
+    ids = list(range(ptr.numel() - 1))
+    shard.batch(ids)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        shard.batch(ids)
+    t.record()
+    torch.cuda.synchronize()
+    us_c = s.elapsed_time(t) * 1e3 / reps
+    ld = (batch.x.size(1) + 3) // 4 * 4
+    moved = 8 * n * ld + 64 * e + 16 * n
+    out.update({"device_collate_us": round(us_c, 1),
+                "device_collate_what": "features, batch vector, edge_index and both CSRs of this batch gathered from a "
+                                       "device-resident packed shard (two launches + one small index upload)",
+                "device_collate_bytes": moved, "device_collate_GBps": round(moved / (us_c * 1e-6) / 1e9, 1)})
+    del shard
+    return out
+
+
 def spawn_workers(args):
     """Start one worker per GPU with torch.distributed.run and pass its output through.  Runs before anything in
     this process has touched the GPU; this process only waits."""
@@ -196,6 +351,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph")
     ap.add_argument("--cpu-sample-graphs", type=int, default=8)
     ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam(fused=True) instead of hgvae_amd.optim.FlatAdam")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the passes after the timed region (fp32-MFMA steps, fresh-batch cost, the other workloads)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -305,7 +462,7 @@ def main():
 
     if rank == 0:
         step_s = elapsed / args.steps
-        pmc = load_pmc(args.workload, n_graphs) if world == 1 else None
+        pmc, pmc_refused = load_pmc(args.workload, n_graphs) if world == 1 else (None, "counter summaries are per single-GPU run")
         h = dims[1]
         recs = probe.durations_ms()
         agg = [(sh, ms) for (k, sh, ms) in recs if k == "agg"]
@@ -324,14 +481,18 @@ def main():
             traffic = None
             if pmc and pmc.get("aggregation", {}).get("F") == f_r:
                 traffic = pmc["aggregation"]["hbm_bytes_per_launch"]
-            hbm_bytes = traffic if traffic is not None else comp
-            achieved = hbm_bytes / (us * 1e-6) / 1e9
+            achieved = comp / (us * 1e-6) / 1e9
             gathered = agg_gather_bytes(n_r, f_r, e_r) / (us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": f"k_aggregate<4,false,*> forward aggregation at F={f_r}",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "bytes": "PMC FETCH_SIZE x2 + WRITE_SIZE per launch" if traffic is not None
-                             else "compulsory bytes (every distinct byte once); no counter summary for this workload",
+                    "traffic_over_compulsory": round(traffic / comp, 3) if traffic is not None else None,
+                    "bytes": "achieved = compulsory bytes of one launch (feature table read once, output written, col, "
+                             "rowptr: every distinct byte once) / average launch time; traffic = PMC FETCH_SIZE x2 + "
+                             "WRITE_SIZE per launch (fabric requests: Infinity-Cache hits included), null without a "
+                             "counter summary measured on these sources",
+                    "pmc_file": pmc.get("file") if pmc else None, "pmc_source_hash": pmc.get("source_hash") if pmc else None,
+                    "pmc_git_commit": pmc.get("git_commit") if pmc else None, "pmc_refused": pmc_refused,
                     "avg_launch_us": round(us, 2), "launches_timed": len(at_h),
                     "compulsory_bytes_per_launch": comp,
                     "gather_bytes_per_launch": agg_gather_bytes(n_r, f_r, e_r),
@@ -385,6 +546,17 @@ def main():
                 roof["step_hbm_frac"] = round(sb / step_s / 1e9 / HBM_PEAK_GBS, 4)
             else:
                 roof["step_hbm_bytes"] = roof["step_hbm_frac"] = None
+        extras = {}
+        if world == 1 and not args.headline_only:
+            # same-run passes after the headline: (1) the step with every projection on the fp32 matrix-core kernels
+            note("fp32-MFMA projection steps")
+            Fn.set_projection("fp32")
+            try:
+                extras["fp32_mfma_ms_per_step"] = round(timed_steps(eager_step, 3, 1), 3)
+            finally:
+                Fn.set_projection(Fn.default_projection())
+            note("fresh-batch cost")
+            extras["fresh_batch"] = fresh_batch_cost(batch, device)
         executed = sum(sh[2] for (k, sh, _) in recs if k in ("agg", "agg_w")) / probe_steps
         sage, gat = reference_aggregations(kind)
         ref_msgs = sage * tot_edges + gat * (tot_edges + tot_nodes)
@@ -392,7 +564,7 @@ def main():
             "metric": "GVAE train graphs/sec", "value": round(tot_graphs / step_s, 2),
             "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3), "higher_is_better": True, "scaling": WORKLOADS[args.workload][1],
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NOTE[Fn.default_projection()], "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][0], "name": args.workload,
                        "graphs_per_gpu": n_graphs, "nodes_per_gpu": n_nodes, "edges_per_gpu": n_edges,
                        "global_batch": int(tot_graphs), "parallelism": f"dp{world}",
@@ -400,8 +572,9 @@ def main():
                                                              f"({bucket.flat.numel()} floats) per step, backend {backend}",
                        "batchnorm": "statistics and running buffers are rank-local (nodes of the local shard); "
                                     "parameters stay identical through the averaged gradients",
-                       "seeds": "weights torch.manual_seed(0) on every rank; graphs 1000 + rank; dropout / eps Philox "
-                                "streams 1234 + rank",
+                       "seeds": "weights torch.manual_seed(0) on every rank; graph g of the job from seed 1000 + g "
+                                "(protein workloads: the union over the ranks is the same set for every N; other "
+                                "workloads 1000 + rank); dropout / eps Philox streams 1234 + rank",
                        "optimizer": "Adam lr=1e-3 (torch fused)" if args.torch_adam else "Adam lr=1e-3 (FlatAdam, torch arithmetic)",
                        "launch": "hip graph replay" if args.graph else "eager"},
             "edge_messages_per_s": round(ref_msgs / step_s, 1),
@@ -413,10 +586,24 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "roofline": roof,
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.cpu_sample_graphs > 0:
             out["cpu_baseline"] = cpu_baseline(batch, kind, dims, args.cpu_sample_graphs)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.headline_only:
+            # (3) the other configurations, a few steps each, so that one run of this script observes all of them
+            import gc
+            del model, opt, bucket, graph, batch, step, eager_step, probe
+            gc.collect()
+            torch.cuda.empty_cache()
+            others = []
+            for name in OTHER_WORKLOADS:
+                if name == args.workload:
+                    continue
+                note(f"secondary workload {name}")
+                others.append(secondary_workload(name, device, captured=name in CAPTURED_TOO))
+            out["workloads"] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         barrier()

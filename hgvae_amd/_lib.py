@@ -76,6 +76,9 @@ SIGNATURES = {
     "hgv_pack16h_bytes": (_sz, [_i32, _i32, _i32]),
     "hgv_pack16h_weights_multi": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgv_gemm_nt16h": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "hgv_row_range_flag": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp]),
+    "hgv_gemm_nt16h_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
+    "hgv_gemm_nt16_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hgv_distance_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hgv_normalized_laplacian": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "hgv_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _vp, _vp, _vp]),

@@ -152,7 +152,9 @@ struct Nt16Args {
     int64_t ntiles;            // 16-row tiles
     int wgs0;                  // two-part launches: workgroups [0, wgs0) work on part 0, the rest on part 1
     int paced;                 // two-part launches: twin waves of the two parts start every row tile together
+    const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
 };
+#define HGV_GATE_EXIT16(a) if ((a).gate != nullptr && ((*(a).gate != 0) ? 1 : 0) != (a).gate_run_if) return
 
 // Progress counters of paced two-part launches: [part][workgroup][wave] = row tiles whose loads have begun.  They are
 // hints only (a stale or missing value costs time, never correctness), so launches may share them.
@@ -378,6 +380,7 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
 template <int NT>
 __global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16Args a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT16(a);
     nt16_body<NT, nt16_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
 }
 
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(64 * nt16_waves<NT>()) void k_gemm_nt16(const Nt16A
 template <int NT0, int NT1>
 __global__ __launch_bounds__(64 * nt16_waves<NT0>()) void k_gemm_nt16_pair(const Nt16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT16(a);
     if ((int)blockIdx.x < a.wgs0) nt16_body<NT0, nt16_ring<NT0>()>(a, lds_raw, 0, blockIdx.x, a.wgs0);
     else nt16_body<NT1, nt16_ring<NT1>()>(a, lds_raw, 1, (int)blockIdx.x - a.wgs0, (int)gridDim.x - a.wgs0);
 }
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(64 * nt16_waves<NT0>()) void k_gemm_nt16_pair(const
 template <int NT>
 __global__ __launch_bounds__(768) void k_gemm_nt16s(const Nt16Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT16(a);
     const Geo16& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
     const int wib = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1234,8 +1239,9 @@ extern "C" int hgv_pack16_weights_multi(int njobs, const float* const* W1, const
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the split-bf16 image.  A1/A2: 16-byte aligned, lda % 4 == 0,
 // lda >= ceil(K/4)*4, pad columns finite; C: 16-byte aligned, ldc % 4 == 0; columns [N, ldc) are written as zeros.
-extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
-                             const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
+static int gemm_nt16_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                         const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
+                         hipStream_t stream) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16: bad sizes");
     if (M == 0) return HGV_OK;
     Nt16Args a{};
@@ -1247,6 +1253,7 @@ extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float*
     HGV_REQUIRE(C && hgv_aligned(C, 16) && ldc % 4 == 0 && ldc >= N, HGV_EINVAL, "gemm_nt16: bad/misaligned output");
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const __bf16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
+    a.gate = gate; a.gate_run_if = gate_run_if;
     const size_t lds = part_bytes16(a.g.tpp, a.g.chunks) + (size_t)a.g.chunks * 64 + 9 * 16 * 4;
     // a part holds exactly its n tiles; the rows of A are streamed once per part
     int rc;
@@ -1262,6 +1269,20 @@ extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float*
     if (rc != HGV_OK) return rc;
     HGV_CHECK_LAUNCH("gemm_nt16");
     return HGV_OK;
+}
+
+extern "C" int hgv_gemm_nt16(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                             const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
+    return gemm_nt16_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream);
+}
+
+// hgv_gemm_nt16 that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the
+// stream); otherwise every workgroup returns at once and C is left untouched.
+extern "C" int hgv_gemm_nt16_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                   const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
+                                   hipStream_t stream) {
+    HGV_REQUIRE(gate != nullptr, HGV_EINVAL, "gemm_nt16_gated: null gate");
+    return gemm_nt16_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, gate, run_if_set ? 1 : 0, stream);
 }
 
 // ---- weight gradients on the bf16 matrix cores (same contract as hgv_gemm_tn / hgv_gemm_tn2) --------------------

@@ -144,7 +144,11 @@ struct NtHArgs {
     int64_t ntiles;
     int wgs0;
     int paced;
+    const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
 };
+
+// every thread of the launch reads the same word, written by an earlier kernel of the stream: a uniform early exit
+#define HGV_GATE_EXIT(a) if ((a).gate != nullptr && ((*(a).gate != 0) ? 1 : 0) != (a).gate_run_if) return
 
 // Progress counters of paced two-part launches (hints only: a stale value costs time, never correctness).
 constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
@@ -408,12 +412,14 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
 template <int NT>
 __global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT(a);
     nth_body<NT, nth_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
 }
 
 template <int NT0, int NT1>
 __global__ __launch_bounds__(64 * nth_waves<NT0>()) void k_gemm_nt16h_pair(const NtHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT(a);
     if ((int)blockIdx.x < a.wgs0) nth_body<NT0, nth_ring<NT0>()>(a, lds_raw, 0, blockIdx.x, a.wgs0);
     else nth_body<NT1, nth_ring<NT1>()>(a, lds_raw, 1, (int)blockIdx.x - a.wgs0, (int)gridDim.x - a.wgs0);
 }
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(64 * nth_waves<NT0>()) void k_gemm_nt16h_pair(const
 template <int NT>
 __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    HGV_GATE_EXIT(a);
     const GeoH& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
     const int wib = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -715,8 +722,9 @@ extern "C" int hgv_pack16h_weights_multi(int njobs, const float* const* W1, cons
 }
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
-extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
-                              const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
+static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                          const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
+                          hipStream_t stream) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -728,6 +736,7 @@ extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float
     HGV_REQUIRE(C && hgv_aligned(C, 16) && ldc % 4 == 0 && ldc >= N, HGV_EINVAL, "gemm_nt16h: bad/misaligned output");
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const _Float16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
+    a.gate = gate; a.gate_run_if = gate_run_if;
     int rc;
     if (a.g.stream) {
         rc = launch_nths(a, stream);
@@ -743,5 +752,73 @@ extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float
     }
     if (rc != HGV_OK) return rc;
     HGV_CHECK_LAUNCH("gemm_nt16h");
+    return HGV_OK;
+}
+
+extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                              const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream);
+}
+
+// hgv_gemm_nt16h that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the
+// stream, e.g. by hgv_row_range_flag); otherwise every workgroup returns at once and C is left untouched.
+extern "C" int hgv_gemm_nt16h_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                    const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
+                                    hipStream_t stream) {
+    HGV_REQUIRE(gate != nullptr, HGV_EINVAL, "gemm_nt16h_gated: null gate");
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, gate, run_if_set ? 1 : 0, stream);
+}
+
+// ---- range guard of the two-piece fp16 split ------------------------------------------------------------------------
+// A row is scaled by one power of two taken from its largest entry; an entry more than 2^16 below it reaches the fp16
+// pieces as a subnormal and keeps an absolute, not a relative, accuracy.  This pass decides, per launch, whether any
+// row of [A1 | A2] holds a non-zero entry more than 2^log2_limit below the row's largest one: flag[0] = 1 if so, else 0.
+namespace {
+__global__ __launch_bounds__(256) void k_row_range(const float* __restrict__ A1, int64_t lda1, int c1, const float* __restrict__ A2,
+                                                   int64_t lda2, int c2, int64_t M, float limit, int* __restrict__ flag) {
+    // 16 lanes per row, 16-byte chunks; exponent arithmetic on the bit patterns (zeros and denormals count as zero)
+    const int sub = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    float amax = 0.f, amin = 3.0e38f;
+    if (row < M) {
+        for (int src = 0; src < 2; ++src) {
+            const float* base = src ? A2 : A1;
+            if (!base) continue;
+            const f32x4* p = reinterpret_cast<const f32x4*>(base + row * (src ? lda2 : lda1));
+            const int nch = src ? c2 : c1;
+            for (int c = sub; c < nch; c += 16) {
+                const f32x4 v = p[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = __builtin_fabsf(v[r]);
+                    amax = fmaxf(amax, x);
+                    amin = x >= 1.17549435e-38f ? fminf(amin, x) : amin;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, d));
+        amin = fminf(amin, __shfl_xor(amin, d));
+    }
+    const bool wide = row < M && amin < 3.0e38f && amax > amin * limit;
+    if (__builtin_amdgcn_ballot_w64(wide) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace
+
+extern "C" int hgv_row_range_flag(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, int64_t M,
+                                  int log2_limit, int* flag, hipStream_t stream) {
+    HGV_REQUIRE(M >= 0 && K1 > 0 && A1 && flag && log2_limit >= 1 && log2_limit <= 60, HGV_EINVAL, "row_range_flag: bad arguments");
+    HGV_REQUIRE(hgv_aligned(A1, 16) && lda1 % 4 == 0 && lda1 >= (K1 + 3) / 4 * 4, HGV_EINVAL, "row_range_flag: bad/misaligned buffer (source 1)");
+    if (A2) HGV_REQUIRE(K2 > 0 && hgv_aligned(A2, 16) && lda2 % 4 == 0 && lda2 >= (K2 + 3) / 4 * 4, HGV_EINVAL,
+                        "row_range_flag: bad/misaligned buffer (source 2)");
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), stream);
+    HGV_REQUIRE(e == hipSuccess, HGV_ELAUNCH, "row_range_flag: memset failed: %s", hipGetErrorString(e));
+    if (M == 0) return HGV_OK;
+    // whole 16-byte chunks are read: pad columns must be zero (they are ignored as zeros)
+    hipLaunchKernelGGL(k_row_range, dim3((unsigned)hgv_cdiv(M * 16, 256)), dim3(256), 0, stream, A1, lda1, (K1 + 3) / 4,
+                       A2, lda2, A2 ? (K2 + 3) / 4 : 0, M, __builtin_ldexpf(1.f, log2_limit), flag);
+    HGV_CHECK_LAUNCH("row_range_flag");
     return HGV_OK;
 }

@@ -77,11 +77,16 @@ class FlatGradBucket:
         adds into ``p.grad``; :meth:`merge_branch` folds it into the bucket after backward."""
         if self.branch_flat is None:
             self.branch_flat = torch.zeros_like(self.flat)
-            off = 0
+            self.branch_views, off = [], 0
             for p in self.params:
                 n = p.numel()
-                p._hgv_branch_grad = self.branch_flat[off:off + n].view_as(p)
+                self.branch_views.append(self.branch_flat[off:off + n].view_as(p))
                 off += n
+        # (re-)claim the parameters: a second bucket over the same parameters points them at its own buffer, so the
+        # bucket whose step runs next calls this again (GraphedTrainStep does at the start of every evaluation)
+        for p, v in zip(self.params, self.branch_views):
+            if getattr(p, "_hgv_branch_grad", None) is not v:
+                p._hgv_branch_grad = v
 
     def merge_branch(self) -> None:
         if self.branch_flat is not None:
@@ -141,6 +146,39 @@ def all_reduce_scalar_mean(t: torch.Tensor, group=None) -> torch.Tensor:
         t = all_reduce_any(t.clone(), group=group)
         t /= dist.get_world_size(group)
     return t
+
+
+def save_checkpoint(model: torch.nn.Module, path: str, bn_buffers: str = "rank0", group=None) -> None:
+    """``torch.save(model.state_dict(), path)`` of the reference (gvae/gvae_skipcon_attention.py:302) for a
+    data-parallel job: every rank calls it, rank 0 writes the file, all ranks leave together.
+
+    Parameters are identical on every rank (same initial weights, averaged gradients).  BatchNorm running statistics
+    are not: each rank tracks the nodes of its own shards.  ``bn_buffers`` states which ones the file holds:
+    ``"rank0"`` (default) rank 0's buffers as they are - what a single-process run over rank 0's shards would have
+    saved; ``"mean"`` the average over the ranks of every floating-point buffer (running_mean, running_var), which for
+    equal shard sizes is the running estimate over all shards up to the between-rank spread of the means;
+    ``num_batches_tracked`` is the same number on every rank.  The model itself is not modified.  The file loads with
+    ``model.load_state_dict(torch.load(path, weights_only=True))`` on any number of ranks, and in the reference."""
+    if bn_buffers not in ("rank0", "mean"):
+        raise ValueError("bn_buffers: 'rank0' or 'mean'")
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    if multi and bn_buffers == "mean":
+        names = {n for n, b in model.named_buffers() if b.is_floating_point()}
+        for k in sorted(names):                                  # same order on every rank
+            state[k] = all_reduce_scalar_mean(state[k], group)
+    if not multi or dist.get_rank(group) == 0:
+        tmp = f"{path}.tmp{os.getpid()}"
+        torch.save({k: v.cpu() for k, v in state.items()}, tmp)
+        os.replace(tmp, path)                                    # a reader never sees a half-written file
+    barrier(group)
+
+
+def load_checkpoint(model: torch.nn.Module, path: str) -> None:
+    """``model.load_state_dict(torch.load(path))`` (gvae/gvae_skipcon.py:327) with a loader that executes nothing
+    from the file; every rank reads the same file."""
+    dev = next(model.parameters()).device
+    model.load_state_dict(torch.load(path, map_location=dev, weights_only=True))
 
 
 def shard_range(num_items: int, rank: int, world: int) -> range:

@@ -177,7 +177,12 @@ def _pack(*specs):
 # cores, fp32 accumulation, exact rescaling: dropped terms <= 3 * 2^-22 per product, measured error at or below the
 # other two kinds.  "bf16x6": three bf16 pieces per operand, six piece products (no scaling, twice the matrix-core
 # work).  "fp32" keeps v_mfma_f32_16x16x4_f32.  Shapes whose split weight image does not fit in LDS use the fp32
-# kernels either way.
+# kernels either way.  "auto": "f16x3" guarded per launch - a pass over the row-count-sized operands looks for a row that
+# holds a non-zero entry more than 2^16 below its largest one (outside that range the two fp16 pieces keep an absolute,
+# not a relative, accuracy); both arithmetics are enqueued behind the device-side flag and exactly one of them runs, with
+# no host round trip.  The test is on the operand alone, so it is conservative: dense normalised activations almost
+# always contain some entry that close to zero and then run as "bf16x6"; it is meant for callers who need the fp32-level
+# bound to hold whatever the weights are, at the price of one more read of the operands and a second image.
 _DEFAULT_PROJECTION = os.environ.get("HGVAE_PROJECTION", "f16x3")
 _projection = _DEFAULT_PROJECTION
 _SPLIT_KINDS = {"bf16x6": ("hgv_gemm_nt16_supported", "hgv_pack16_bytes", "hgv_pack16_weights_multi", "hgv_gemm_nt16"),
@@ -190,8 +195,8 @@ def default_projection() -> str:
 
 def set_projection(kind: str) -> None:
     global _projection
-    if kind not in ("bf16x6", "f16x3", "fp32"):
-        raise ValueError("projection arithmetic is 'bf16x6', 'f16x3' or 'fp32'")
+    if kind not in ("bf16x6", "f16x3", "fp32", "auto"):
+        raise ValueError("projection arithmetic is 'bf16x6', 'f16x3', 'auto' or 'fp32'")
     _projection = kind
 
 
@@ -199,13 +204,19 @@ _array_types: dict = {}
 _split_sizes: dict = {}
 
 
-def _split_image_floats(n: int, k1: int, k2: int) -> int:
-    """Size (in floats) of the split-bf16 image of an n x (k1 + k2) weight, 0 when the NT kernel does not take the shape."""
-    key = (_projection, n, k1, k2)
+def _split_kind() -> Optional[str]:
+    """The split arithmetic single images are packed for now ('auto' packs 'f16x3' and 'bf16x6' side by side)."""
+    return _projection if _projection in _SPLIT_KINDS else ("f16x3" if _projection == "auto" else None)
+
+
+def _split_image_floats(n: int, k1: int, k2: int, kind: Optional[str] = None) -> int:
+    """Size (in floats) of the split image of an n x (k1 + k2) weight, 0 when the NT kernel does not take the shape."""
+    kind = kind or _split_kind()
+    key = (kind, n, k1, k2)
     v = _split_sizes.get(key)
     if v is None:
         lib = _lib.load()
-        supported, nbytes, _, _ = _SPLIT_KINDS[_projection]
+        supported, nbytes, _, _ = _SPLIT_KINDS[kind]
         v = _split_sizes[key] = getattr(lib, nbytes)(n, k1, k2) // 4 if getattr(lib, supported)(n, k1, k2) else 0
     return v
 
@@ -231,13 +242,18 @@ class _Image:
 PACK_MAX_JOBS = 24           # images per hgv_pack16_weights_multi launch
 
 
-def _pack_split(jobs) -> list:
-    """Split-bf16 images of ``jobs`` = [(wa, wb, transposed, n, k1, k2), ...], one launch per PACK_MAX_JOBS of them."""
+def _pack_split(jobs, kind: Optional[str] = None) -> list:
+    """Split images of ``jobs`` = [(wa, wb, transposed, n, k1, k2), ...], one launch per PACK_MAX_JOBS of them."""
+    kind = kind or _split_kind()
+    if _projection == "auto" and kind == "f16x3":
+        # both arithmetics side by side; the product picks one per launch on the device
+        return [_Image("auto", h.a, b.a) for h, b in zip(_pack_split(jobs, "f16x3+"), _pack_split(jobs, "bf16x6"))]
+    kind = kind.rstrip("+")
     out = []
     for j0 in range(0, len(jobs), PACK_MAX_JOBS):
         part = jobs[j0:j0 + PACK_MAX_JOBS]
         nj = len(part)
-        sizes = [_split_image_floats(n, k1, k2) for (_, _, _, n, k1, k2) in part]
+        sizes = [_split_image_floats(n, k1, k2, kind) for (_, _, _, n, k1, k2) in part]
         buf = torch.empty(sum(sizes), dtype=torch.float32, device=part[0][0].device)
         vp_t, i64_t, i32_t = _ctypes_arrays(nj)
         W1, W2, Op = vp_t(), vp_t(), vp_t()
@@ -247,14 +263,14 @@ def _pack_split(jobs) -> list:
         for q, ((wa, wb, t, n, k1, k2), sz) in enumerate(zip(part, sizes)):
             piece = buf[off:off + sz]
             off += sz
-            out.append(_Image(_projection, piece))
+            out.append(_Image(kind, piece))
             W1[q], Op[q] = wa.data_ptr(), piece.data_ptr()
             sn1[q], sk1[q] = (wa.stride(1), wa.stride(0)) if t else (wa.stride(0), wa.stride(1))
             if wb is not None:
                 W2[q] = wb.data_ptr()
                 sn2[q], sk2[q] = (wb.stride(1), wb.stride(0)) if t else (wb.stride(0), wb.stride(1))
             K1[q], K2[q], N[q] = k1, k2, n
-        _lib.call(_SPLIT_KINDS[_projection][2], nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
+        _lib.call(_SPLIT_KINDS[kind][2], nj, W1, sn1, sk1, K1, W2, sn2, sk2, K2, N, Op, _lib.stream())
     return out
 
 
@@ -312,7 +328,7 @@ def weight_images(owner):
     of the next evaluation.  Nothing outlives the context except the plan (weak references and shapes), so an image
     can never be older than the evaluation that uses it.  Only leaf parameters are planned."""
     global _image_scope
-    if _projection not in _SPLIT_KINDS:
+    if _projection not in _SPLIT_KINDS:        # fp32 images, or 'auto' (two images per weight): packed where they are used
         yield
         return
     attr = "_hgv_image_plan_grad" if torch.is_grad_enabled() else "_hgv_image_plan_nograd"
@@ -353,7 +369,8 @@ def _images(*specs) -> list:
         wa, wb, t = sp
         n, k1 = (wa.size(1), wa.size(0)) if t else (wa.size(0), wa.size(1))
         k2 = 0 if wb is None else (wb.size(0) if t else wb.size(1))
-        if _projection in _SPLIT_KINDS and _split_image_floats(n, k1, k2) > 0:
+        if _split_kind() is not None and _split_image_floats(n, k1, k2) > 0 and \
+                (_projection != "auto" or _split_image_floats(n, k1, k2, "bf16x6") > 0):
             if scope is not None and _plannable(wa) and _plannable(wb):
                 key = (_wkey(wa), _wkey(wb), t)
                 if key not in scope.requests:
@@ -413,7 +430,15 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     if ev:
         ev[0].record()
-    if img.kind in _SPLIT_KINDS:
+    if img.kind == "auto":
+        # one pass over the operands decides on the device; both products are enqueued and exactly one of them runs
+        flag = _workspace(256, xa.device, "range_flag")
+        a2 = (_lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0)
+        _lib.call("hgv_row_range_flag", xa.data_ptr(), ld_of(xa), xa.size(1), *a2, m, 16, flag.data_ptr(), _lib.stream())
+        for name, image, run_if_set in (("hgv_gemm_nt16h_gated", img.a, 0), ("hgv_gemm_nt16_gated", img.b, 1)):
+            _lib.call(name, xa.data_ptr(), ld_of(xa), xa.size(1), *a2, image.data_ptr(), _lib.ptr(bias), m, n_out,
+                      out.data_ptr(), ld_of(out), flag.data_ptr(), run_if_set, _lib.stream())
+    elif img.kind in _SPLIT_KINDS:
         _lib.call(_SPLIT_KINDS[img.kind][3], xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
                   ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
                   _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), _lib.stream())
@@ -446,6 +471,7 @@ def direct_weight_grads(enabled: bool = True):
 
 
 _trunk_stream: Optional[int] = None      # raw handle of the stream the step runs on while part of it runs on a branch stream
+_in_branch = False                       # True only while the operators of a branch are being created (forward side)
 
 
 @contextlib.contextmanager
@@ -453,21 +479,33 @@ def branch_of(trunk: "torch.cuda.Stream"):
     """Marks the operators created inside (with another stream current) as a branch next to ``trunk``: in their
     backward pass - which autograd runs on the branch stream, possibly at the same time as the trunk's - weight and
     bias gradients are returned to autograd instead of being added into ``.grad`` by the kernels (see
-    :func:`direct_weight_grads`), and weight images packed on the spot are not shared across the two streams."""
+    :func:`direct_weight_grads`), and weight images packed on the spot are not shared across the two streams.
+    The trunk handle outlives the context - the backward pass comes later - until :func:`end_branches` (called by the
+    step that owns the branch after its backward pass) or the next :func:`no_branches`; the forward-side decisions
+    (BatchNorm running statistics through stand-ins) are taken only inside the context."""
+    global _trunk_stream, _in_branch
+    _trunk_stream = trunk.cuda_stream
+    prev, _in_branch = _in_branch, True
+    try:
+        yield
+    finally:
+        _in_branch = prev
+
+
+def end_branches() -> None:
+    """The backward pass of a branched evaluation is over: later operators on any stream are ordinary ones."""
     global _trunk_stream
-    _trunk_stream = trunk.cuda_stream      # stays set after the context: the backward pass comes later
-    yield
+    _trunk_stream = None
 
 
 def no_branches() -> None:
     """The evaluation that starts now runs on one stream (forgets the trunk of an earlier branched evaluation)."""
-    global _trunk_stream
-    _trunk_stream = None
+    end_branches()
     _branch_updates.clear()
 
 
 def on_branch_stream() -> bool:
-    return _trunk_stream is not None and _lib.stream() != _trunk_stream
+    return _in_branch and _trunk_stream is not None and _lib.stream() != _trunk_stream
 
 
 _branch_updates: list = []      # (BatchNorm module, [2, H] stand-in holding momentum * (mean, unbiased variance), momentum)
@@ -523,7 +561,7 @@ _tn_f16 = os.environ.get("HGVAE_TN_F16", "0") == "1"
 def _tn16_ok(m, n, k1, k2, *mats) -> bool:
     """Weight gradients run on the 16-bit matrix cores (split operands, fp32-accurate) when the projection
     arithmetic is a split kind, the shape is one the kernel covers and the operands are 16-byte aligned."""
-    if _projection not in _SPLIT_KINDS or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
+    if (_projection not in _SPLIT_KINDS and _projection != "auto") or not _lib.load().hgv_gemm_tn16_supported(m, n, k1, k2):
         return False
     return all(t.data_ptr() % 16 == 0 and ld_of(t) % 4 == 0 for t in mats)
 

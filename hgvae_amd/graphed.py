@@ -19,7 +19,7 @@ from typing import Callable, Optional
 import torch
 
 from .distributed import FlatGradBucket
-from .functional import direct_weight_grads
+from .functional import direct_weight_grads, end_branches
 from .graph import graph_of
 from .noise import PhiloxNoise, use_noise
 from .vae import train_step_loss
@@ -39,6 +39,8 @@ class GraphedTrainStep:
                  warmup: int = 3):
         self.model, self.optimizer = model, optimizer
         self.x, self.edge_index, self.batch, self.lambda_kl, self.loss_fn = x, edge_index, batch, lambda_kl, loss_fn
+        if bucket is None:                # an optimizer that owns a flat bucket (FlatAdam) reads its gradients there
+            bucket = getattr(optimizer, "bucket", None)
         self.bucket = bucket if bucket is not None else FlatGradBucket(model.parameters())
         self.bucket.enable_branch()
         dev = x.device
@@ -57,15 +59,25 @@ class GraphedTrainStep:
             from .optim import FlatAdam
             lazy_state = not isinstance(optimizer, FlatAdam)    # torch optimizers create their state in step()
             keep = [(t, t.clone()) for t in list(model.buffers()) + (list(model.parameters()) if lazy_state else [])]
+            # the optimizer may already have trained (an earlier capture, eager steps, load_state_dict): what it holds
+            # now is put back after the throw-away steps; only state that those steps created starts from zero
+            state_before = {p: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in st.items()}
+                            for p, st in optimizer.state.items()} if lazy_state else {}
             for _ in range(warmup):
                 self._body(step_optimizer=lazy_state, reduce=True)
             with torch.no_grad():
                 for t, saved in keep:
                     t.copy_(saved)
-                if lazy_state:      # the state tensors now exist; put them back to "no step taken"
-                    for st in optimizer.state.values():
-                        for v in st.values():
-                            if isinstance(v, torch.Tensor):
+                if lazy_state:
+                    for p, st in optimizer.state.items():
+                        old = state_before.get(p, {})
+                        for k, v in list(st.items()):
+                            if k in old:
+                                if isinstance(v, torch.Tensor):
+                                    v.copy_(old[k])
+                                else:
+                                    st[k] = old[k]
+                            elif isinstance(v, torch.Tensor):      # created by the warm-up: "no step taken"
                                 v.zero_()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
@@ -75,6 +87,7 @@ class GraphedTrainStep:
 
     def _body(self, step_optimizer: bool, reduce: bool):
         self.noise.advance()
+        self.bucket.enable_branch()       # another bucket over the same parameters may have claimed the branch views since
         self.bucket.zero()
         with use_noise(self.noise):
             loss = self.loss_fn(self.model, self.x, self.edge_index, self.batch, self.lambda_kl)
@@ -83,6 +96,7 @@ class GraphedTrainStep:
             # accumulation nodes of the capture stream from there, on purpose
             warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
             loss.backward()
+        end_branches()                    # branch membership ends with the step that created it
         self.bucket.merge_branch()
         if reduce:
             self.bucket.all_reduce_mean()
@@ -158,6 +172,10 @@ class CapturedTraining:
         self._eval_entries: list = []       # the same for evaluation steps (GraphedEvalStep)
         self._bucket = getattr(optimizer, "bucket", None)
         self.captured_steps = self.eager_steps = 0
+        # ranks draw different dropout / eps streams (the Philox counters are (row, chunk, offset): one seed on every
+        # rank would repeat the same noise at the same positions of every shard)
+        import torch.distributed as dist
+        self._rank_term = 1_000_003 * (dist.get_rank() if dist.is_available() and dist.is_initialized() else 0)
 
     def _find(self, data, entries=None):
         sid = getattr(data, "structure_id", None)
@@ -183,7 +201,7 @@ class CapturedTraining:
         ei = data.edge_index.clone()
         bt = data.batch.clone() if data.batch is not None else None
         step = GraphedTrainStep(self.model, self.optimizer, x, ei, bt, self.lambda_kl, loss_fn=self.loss_fn,
-                                bucket=self._bucket, seed=self.seed + 7919 * len(self._entries))
+                                bucket=self._bucket, seed=self.seed + 7919 * len(self._entries) + self._rank_term)
         self._bucket = step.bucket
         self._entries.append((getattr(data, "structure_id", None), ei, bt, step))
         return step
@@ -196,9 +214,16 @@ class CapturedTraining:
             step = self._capture(data)
         if step is None:
             self.eager_steps += 1
-            self.optimizer.zero_grad()
+            # gradients must stay in the bucket's views: a captured step of this object (replayed before or after this
+            # one) writes them there, and zero_grad() of a torch optimizer would detach p.grad from the views
+            if self._bucket is not None:
+                self._bucket.zero()
+            else:
+                self.optimizer.zero_grad()
             loss = self.loss_fn(self.model, data.x, data.edge_index, data.batch, self.lambda_kl)
             loss.backward()
+            if self._bucket is not None:
+                self._bucket.all_reduce_mean()
             self.optimizer.step()
             return loss.detach()
         self.captured_steps += 1
@@ -230,14 +255,16 @@ class CapturedTraining:
         n = 0
         for data in loader:
             data = _to_device(data, dev)
-            step = self._find(data, self._eval_entries)
+            # a captured evaluation has its KL weight baked in: entries are looked up per weight
+            entries = [e for e in self._eval_entries if e[3].lambda_kl == lambda_kl]
+            step = self._find(data, entries)
             if step is None and len(self._eval_entries) < self.max_structures:
                 x = new_padded(data.x.size(0), data.x.size(1), dev)
                 x.copy_(data.x)
                 ei = data.edge_index.clone()
                 bt = data.batch.clone() if data.batch is not None else None
                 step = GraphedEvalStep(self.model, x, ei, bt, lambda_kl, loss_fn=self.loss_fn,
-                                       seed=self.seed + 104729 * (len(self._eval_entries) + 1))
+                                       seed=self.seed + 104729 * (len(self._eval_entries) + 1) + self._rank_term)
                 self._eval_entries.append((getattr(data, "structure_id", None), ei, bt, step))
             if step is None:
                 with torch.no_grad():

@@ -117,6 +117,16 @@ class GraphShard:
     def __len__(self) -> int:
         return len(self._node_ptr_host) - 1
 
+    _next_token = 0
+
+    def _token(self) -> int:
+        """Process-wide serial number of this shard (never reused, unlike ``id()`` after a shard is collected)."""
+        t = getattr(self, "_serial", None)
+        if t is None:
+            t = self._serial = GraphShard._next_token
+            GraphShard._next_token += 1
+        return t
+
     @property
     def uniform(self) -> bool:
         """True when every graph of the shard has the same nodes and edges (frames of one molecule): then all batches
@@ -178,7 +188,7 @@ class GraphShard:
         out.ptr = d_nptr
         out.num_graphs = b
         if self.uniform:
-            out.structure_id = ("uniform", id(self), b)
+            out.structure_id = ("uniform", self._token(), b)
         if with_csr:
             out.graph = Graph.from_parts(ei, n_out, _Csr(rp_d, col_d, perm_d), _Csr(rp_s, col_s, perm_s))
         return out

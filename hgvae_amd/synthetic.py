@@ -49,6 +49,19 @@ def protein_like_batch(num_graphs: int, seed: int, device, nodes=(4500, 5500), m
     return Batch.from_data_list([protein_like_graph(n, mean_degree, f_in, gen, device) for n in sizes])
 
 
+def protein_like_batch_by_index(graph_ids, base_seed: int, device, nodes=(4500, 5500), mean_degree: int = 12,
+                                f_in: int = 105) -> Batch:
+    """The graphs ``graph_ids`` of an unbounded seeded data set: graph g (size included) is a function of
+    ``base_seed + g`` alone, so any partition of a range of ids over processes yields the same graphs as one process
+    drawing the whole range."""
+    items = []
+    for g in graph_ids:
+        gen = torch.Generator(device=device).manual_seed(int(base_seed) + int(g))
+        n = int(torch.randint(nodes[0], nodes[1] + 1, (1,), generator=gen, device=device).item())
+        items.append(protein_like_graph(n, mean_degree, f_in, gen, device))
+    return Batch.from_data_list(items)
+
+
 def local_random_graph(n: int, degree: int, f: int, seed: int, device, window: int = 512, far: float = 0.2) -> Batch:
     gen = torch.Generator(device=device).manual_seed(seed)
     e = n * degree

@@ -353,6 +353,7 @@ def train_vae_custom_pool(model, loader, optimizer, clip_value=None, device=None
 
 
 def custom_pool_step_loss(model, x, edge_index, batch):
+    Fn.no_branches()
     with Fn.weight_images(model):
         with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
             reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)

@@ -332,6 +332,21 @@ int hgv_pack16h_weights_multi(int njobs, const float* const* W1, const int64_t* 
 int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                    const float* bias, int64_t M, int N, float* C, int64_t ldc, hgv_stream_t stream);
 
+/* Range guard of the two-piece fp16 split (no counterpart in the reference: it serves the "auto" projection arithmetic of
+ * the lin_l / lin_r / Linear products, gvae/gvae_skipcon.py:61-100).  hgv_row_range_flag sets flag[0] (device int) to 1
+ * when some row of [A1 | A2] (A2 nullable; buffer rules of hgv_gemm_nt16h) holds a non-zero entry more than 2^log2_limit
+ * below the largest entry of that row, else to 0.  The _gated products are hgv_gemm_nt16h / hgv_gemm_nt16 that do their
+ * work only when (*gate != 0) == run_if_set and otherwise leave C untouched, so a caller can enqueue both arithmetics
+ * behind one flag without a host round trip: exactly one of them writes C. */
+int hgv_row_range_flag(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, int64_t M, int log2_limit,
+                       int* flag, hgv_stream_t stream);
+int hgv_gemm_nt16h_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                         const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
+                         hgv_stream_t stream);
+int hgv_gemm_nt16_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                        const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
+                        hgv_stream_t stream);
+
 /* Weight gradients of the same projections on the bf16 matrix cores (three-piece split of both operands, six piece
  * products, fp32 accumulation per row slice, fp64 across slices): contract of hgv_gemm_tn2 with A2 / GW2 nullable, plus
  * 16-byte aligned G / A1 / A2 with leading dimensions that are multiples of 4.  hgv_gemm_tn16_supported: 1 for shapes

@@ -52,6 +52,28 @@ def main():
     run_shard(model, bucket, rank, dev)
     bucket.all_reduce_mean()
     torch.cuda.synchronize()
+    # the benchmark's sharded workload: graph g comes from seed base + g, so the ranks' shards put together are the
+    # graphs one process would have drawn (per-graph node count and feature sum, summed over the ranks)
+    from hgvae_amd import synthetic
+    from hgvae_amd.distributed import all_reduce_any, shard_range
+    total = 2 * world + 1
+    ids = shard_range(total, rank, world)
+    kw = dict(nodes=(30, 50), mean_degree=4, f_in=14)
+    part = synthetic.protein_like_batch_by_index(ids, 1000, dev, **kw)
+    marks = torch.zeros(total, 3, dtype=torch.float64, device=dev)
+    pp = part.ptr.tolist()
+    for k, g in enumerate(ids):
+        blk = part.x[pp[k]:pp[k + 1]].double()
+        marks[g] = torch.stack([torch.tensor(float(pp[k + 1] - pp[k]), device=dev, dtype=torch.float64), blk.sum(), blk.square().sum()])
+    all_reduce_any(marks)
+    union_ok = True
+    if rank == 0:
+        whole = synthetic.protein_like_batch_by_index(range(total), 1000, dev, **kw)
+        wp = whole.ptr.tolist()
+        want = torch.stack([torch.stack([torch.tensor(float(wp[g + 1] - wp[g]), device=dev, dtype=torch.float64),
+                                         whole.x[wp[g]:wp[g + 1]].double().sum(), whole.x[wp[g]:wp[g + 1]].double().square().sum()])
+                            for g in range(total)])
+        union_ok = bool(torch.equal(marks, want))
     ok, worst = True, 0.0
     if rank == 0:
         ref = SkipconVAE(12, 32, 4).to(dev).train()
@@ -67,8 +89,8 @@ def main():
         acc /= world
         worst = float((acc - bucket.flat).abs().max())
         scale = float(acc.abs().max())
-        ok = worst <= 1e-6 * scale and bufs_equal
-        print(json.dumps({"world": world, "backend": dist.get_backend(), "max_abs_diff": worst, "grad_scale": scale,
+        ok = worst <= 1e-6 * scale and bufs_equal and union_ok
+        print(json.dumps({"world": world, "sharded_workload_union_equals_one_process_batch": union_ok, "backend": dist.get_backend(), "max_abs_diff": worst, "grad_scale": scale,
                           "rank0_bn_buffers_equal_single_process": bufs_equal, "ok": ok}), flush=True)
     barrier()
     dist.destroy_process_group()

@@ -739,6 +739,44 @@ def test_scaled_fp16_products_keep_fp32_accuracy(case, widths, tn_f16, monkeypat
         Fn.set_projection(Fn.default_projection())
 
 
+@pytest.mark.parametrize("log2_range", [17, 20, 24, 30])
+def test_scaled_fp16_products_small_entries_behind_a_large_one(log2_range):
+    """The input-conditional clause of the f16x3 projections, pinned.  A row is scaled by ONE power of two chosen from its
+    largest entry, so an entry more than 2^16 below that maximum reaches the fp16 pieces as a subnormal: it keeps an
+    ABSOLUTE accuracy of 2^(e - 37) (e = floor(log2 of the row maximum)), not a relative one.  The adversarial pairing
+    puts zero weights against the large entries, so the result consists of the small entries only and the usual measure
+    (error / sum of |terms|) no longer hides the loss: the documented bound must hold, the error must really exceed the
+    fp32-level bar where the clause applies (else the clause could be dropped), and the six-product bf16 kernel and the
+    'auto' arithmetic - which sends such a launch to that kernel - must stay at fp32 level."""
+    from hgvae_amd import functional as Fn
+    m, k, n = 3000, 138, 138
+    gen = torch.Generator(device=dev()).manual_seed(1000 + log2_range)
+    big = 1.0e6
+    small = big * 2.0 ** (-log2_range)
+    x = (torch.rand(m, k, device=dev(), generator=gen) + 0.5) * small
+    x[:, ::32] = big * (torch.rand(m, (k + 31) // 32, device=dev(), generator=gen) + 1.0)     # one large entry per 32-wide k chunk
+    w = torch.randn(n, k, device=dev(), generator=gen)
+    w[:, ::32] = 0.0                                                                          # ... meets a zero weight
+    xa = Fn.as_padded(x)
+    want = x.double() @ w.double().t()
+    terms = x.double().abs() @ w.double().abs().t()
+    e = torch.floor(torch.log2(x.abs().amax(dim=1, keepdim=True).double()))
+    clause = w.double().abs().sum(dim=1).unsqueeze(0) * torch.exp2(e - 37)                    # sum_k |w_nk| 2^(e - 37)
+    errs = {}
+    try:
+        for kind in ("f16x3", "bf16x6", "auto"):
+            Fn.set_projection(kind)
+            y = Fn._gemm_nt(xa, Fn._image(w, None, False), None, None, n)
+            errs[kind] = (y[:, :n].double() - want).abs()
+    finally:
+        Fn.set_projection(Fn.default_projection())
+    assert float((errs["f16x3"] / (clause + 1e-6 * terms)).max()) <= 1.0, "f16x3 beyond its documented absolute bound"
+    assert float((errs["bf16x6"] / terms).max()) <= 1e-6
+    assert float((errs["auto"] / terms).max()) <= 1e-6, "the guarded arithmetic must route this launch to the six-product kernel"
+    if log2_range >= 24:
+        assert float((errs["f16x3"] / terms).max()) > 1e-5       # the clause is real: fp32 would be exact to 1e-7 here
+
+
 @pytest.mark.parametrize("m,n,k1,k2", [(1, 5, 3, 2), (4, 16, 16, 16), (5, 17, 33, 7), (37, 138, 138, 28), (1000, 56, 138, 138),
                                        (4099, 138, 105, 105), (3001, 276, 138, 6), (2500, 1, 276, 138), (9000, 256, 256, 256),
                                        (6000, 138, 276, 138), (5000, 150, 144, 145),

@@ -431,7 +431,7 @@ def test_captured_training_epochs_learn_and_fall_back():
     shard = GraphShard.from_data_list(frames, dev)
     assert shard.uniform
     loader = shard.loader(8)                              # 8 + 8 + 6 graphs
-    assert next(iter(loader)).structure_id == ("uniform", id(shard), 8)
+    assert next(iter(loader)).structure_id == ("uniform", shard._token(), 8)
     torch.manual_seed(61)
     model = SkipconVAE(12, 32, 4).to(dev).train()
     opt = FlatAdam(model.parameters(), lr=1e-2, capturable=True)
@@ -483,3 +483,103 @@ def test_captured_validation_matches_validate_vae():
     after = cap.validate_epoch(batches)
     assert abs(after - validate_vae(model, batches)) <= 3 * spread + 1e-3 * abs(after) + 0.05 * abs(after)
     assert after < mid
+
+
+def test_second_capture_keeps_the_optimizer_state():
+    """A new batch structure is captured in the middle of training (the smaller last batch of an epoch): the throw-away
+    steps of that capture must leave Adam's moments and step count as they were, not reset them."""
+    from hgvae_amd.graphed import CapturedTraining
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    full, last = _frames(3, 6, 23, 12, seed=80), _frames(1, 4, 23, 12, seed=81)
+    torch.manual_seed(80)
+    model = SkipconVAE(12, 32, 4).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    cap = CapturedTraining(model, opt, seed=3)
+    for data in full:
+        cap.step(data)
+    w = model.encoder1[0].lin_l.weight
+    st = opt.state[w]
+    assert float(st["step"]) == 3.0
+    before = {k: v.clone() for k, v in st.items()}
+    params_before = [p.detach().clone() for p in model.parameters()]
+    from hgvae_amd.graphed import GraphedTrainStep
+    x = last[0].x
+    GraphedTrainStep(model, opt, x, last[0].edge_index, last[0].batch, bucket=cap._bucket, seed=9)     # capture only
+    for k, v in opt.state[w].items():
+        assert torch.equal(v, before[k]), k
+    for p, q in zip(model.parameters(), params_before):
+        assert torch.equal(p.detach(), q)
+    cap.step(last[0])                                  # second structure through the epoch driver: one real step
+    assert len(cap._entries) == 2 and float(opt.state[w]["step"]) == 4.0
+    assert float(opt.state[w]["exp_avg"].abs().max()) > 0
+
+
+def test_eager_fallback_keeps_gradients_in_the_bucket():
+    """An eager step between captured ones, with an optimizer that is stepped outside the graph (plain torch Adam): the
+    fallback must not detach p.grad from the bucket's views, or the next replay's gradients would be overwritten by the
+    stale eager ones when the bucket is gathered."""
+    from hgvae_amd.graphed import CapturedTraining
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    a, b = _frames(2, 5, 19, 12, seed=82), _frames(1, 3, 31, 12, seed=83)
+    torch.manual_seed(82)
+    model = SkipconVAE(12, 32, 4).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)          # not capturable: stepped after the replay
+    cap = CapturedTraining(model, opt, seed=4, max_structures=1)
+    cap.step(a[0])
+    cap.step(b[0])                                      # second structure, budget used up: eager
+    assert cap.eager_steps == 1
+    bucket = cap._bucket
+    for p, v in zip(bucket.params, bucket.views):
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+    stale = bucket.flat.clone()
+    entry = cap._entries[0][3]
+    entry.x.copy_(a[1].x)
+    entry.graph.replay()                                # gradients of the new batch, written into the bucket
+    fresh = bucket.flat.clone()
+    assert not torch.equal(fresh, stale)
+    bucket.all_reduce_mean()                            # what __call__ does next: must leave the fresh gradients alone
+    assert torch.equal(bucket.flat, fresh)
+    for p, v in zip(bucket.params, bucket.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+
+
+def test_branch_membership_ends_with_the_captured_step():
+    """A captured step runs its second encode pass as a branch; afterwards an ordinary training-mode forward on any
+    stream updates the BatchNorm running statistics itself (nothing is left parked in stand-ins)."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graphed import GraphedTrainStep
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    data = _frames(1, 6, 23, 12, seed=84)[0]
+    torch.manual_seed(84)
+    model = SkipconVAE(12, 32, 4).to(dev).train()
+    opt = FlatAdam(model.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(model, opt, data.x, data.edge_index, data.batch, seed=2)
+    step()
+    torch.cuda.synchronize()
+    assert Fn._trunk_stream is None and not Fn.on_branch_stream()
+    bn = model.encoder2[2]
+    rm, count = bn.running_mean.clone(), int(bn.num_batches_tracked)
+    model(data.x, data.edge_index, data.batch)          # eager, default stream, train mode
+    torch.cuda.synchronize()
+    assert int(bn.num_batches_tracked) == count + 1
+    assert not torch.equal(bn.running_mean, rm)
+    assert not Fn._branch_updates
+
+
+def test_captured_validation_is_keyed_by_the_kl_weight():
+    from hgvae_amd.graphed import CapturedTraining
+    from hgvae_amd.optim import FlatAdam
+    from hgvae_amd.vae import SkipconVAE
+    dev = torch.device("cuda:0")
+    batches = _frames(2, 4, 17, 12, seed=85)
+    torch.manual_seed(85)
+    model = SkipconVAE(12, 32, 4).to(dev).train()
+    cap = CapturedTraining(model, FlatAdam(model.parameters(), lr=1e-3, capturable=True), seed=1)
+    one = cap.validate_epoch(batches, lambda_kl=1.0)
+    zero = cap.validate_epoch(batches, lambda_kl=0.0)
+    assert len(cap._eval_entries) == 2
+    assert zero < one                                   # the KL term is positive and was dropped

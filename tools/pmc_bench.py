@@ -31,7 +31,7 @@ def run_pass(counters, workload, steps, out, extra):
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["timeout", "-s", "KILL", "240", "rocprofv3", "--pmc", *counters, "-d", d, "-o", "p", "--output-format", "csv",
            "--", "python3", os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", "2",
-           "--no-cpu-baseline"] + extra
+           "--no-cpu-baseline", "--headline-only"] + extra
     log = open(d + ".log", "w")
     rc = subprocess.run(cmd, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT).returncode
     if rc != 0:
@@ -86,7 +86,10 @@ def main():
 
     in_step = [k for k in per_step if disp.get(k, 0) > 0]
     graphs = line["config"]["graphs_per_gpu"] if line else None
-    doc = {"workload": args.workload, "graphs_per_gpu": graphs,
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = {"workload": args.workload, "graphs_per_gpu": graphs, "source_hash": bench.source_hash(),
+           "git_commit": os.environ.get("HGVAE_GIT_COMMIT"),
            "nodes": line["config"]["nodes_per_gpu"] if line else None, "edges": line["config"]["edges_per_gpu"] if line else None,
            "source": f"tools/pmc_bench.py: rocprofv3 --pmc <counter> -- python3 bench.py --workload {args.workload} "
                      f"--steps {{{lo},{hi}}} --warmup 2 (separate passes; per-step = difference / {hi - lo})",
