@@ -54,19 +54,20 @@ def pca_fit_transform(x: torch.Tensor, n_components: int = 10, col_sum: Optional
     c = (col_sum if col_sum is not None else x.sum(dim=0)) / m
     gen = torch.Generator(device=x.device).manual_seed(seed)
     q = torch.linalg.qr(torch.randn(n, b, dtype=torch.float64, device=x.device, generator=gen)).Q
-    prev, settled = None, False
+    prev, settled, drift = None, False, float("inf")
     for _ in range(max(iters, 1)):
         y = x @ q - (c @ q).unsqueeze(0)                       # centred matrix times q   [m, b]
         z = x.t() @ y - torch.outer(c, y.sum(dim=0))           # its transpose times y    [n, b]
         q, r = torch.linalg.qr(z)
         ritz = r.diagonal().abs()[:k]
-        if prev is not None and bool(((ritz - prev).abs() <= tol * ritz.max()).all()):
-            settled = True
-            break
+        if prev is not None:
+            drift = float(((ritz - prev).abs().max() / ritz.max()).item())      # one read-back per round, as the stopping test needs
+            if drift <= tol:
+                settled = True
+                break
         prev = ritz
-    if not settled and iters > 1:
+    if not settled and iters > 1 and drift > 1e3 * tol:
         import warnings
-        drift = float(((ritz - prev).abs().max() / ritz.max()).item()) if prev is not None else float("nan")
         warnings.warn(f"pca_fit_transform: the subspace iteration stopped after {iters} rounds with the Ritz values still "
                       f"moving by {drift:.1e} (relative; tol {tol:.1e}); raise iters or oversample for tighter scores",
                       RuntimeWarning, stacklevel=2)

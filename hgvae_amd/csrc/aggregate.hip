@@ -65,7 +65,20 @@ struct AggArgs {
     float* out;
     int64_t ldo;
     int long_threshold;    // > 0: rows with more entries than this are left to k_aggregate_long
+    // optional column affine of the SOURCE rows, applied to the finished row instead: with x = a * col_s + col_t column by
+    // column, the mean over the neighbours' x rows is (mean over their a rows) * col_s + col_t for a row with neighbours and
+    // 0 for a row without (row_mode 1 only); col_s / col_t hold nchunks * VEC floats
+    const float* col_s; const float* col_t;
 };
+
+__device__ __forceinline__ void vaffine(float& a, const float* s, const float* t, bool any) { a = __fmaf_rn(a, s[0], any ? t[0] : 0.f); }
+__device__ __forceinline__ void vaffine(float2& a, const float* s, const float* t, bool any) {
+    a.x = __fmaf_rn(a.x, s[0], any ? t[0] : 0.f); a.y = __fmaf_rn(a.y, s[1], any ? t[1] : 0.f);
+}
+__device__ __forceinline__ void vaffine(float4& a, const float* s, const float* t, bool any) {
+    a.x = __fmaf_rn(a.x, s[0], any ? t[0] : 0.f); a.y = __fmaf_rn(a.y, s[1], any ? t[1] : 0.f);
+    a.z = __fmaf_rn(a.z, s[2], any ? t[2] : 0.f); a.w = __fmaf_rn(a.w, s[3], any ? t[3] : 0.f);
+}
 
 // NB neighbour rows (x CPL chunks) of one segment position in flight per lane; adds stay in segment order
 template <int VEC, bool WEIGHTED, int CPL, int NB>
@@ -145,6 +158,7 @@ __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
         for (int q = 0; q < CPL; ++q) {
             if (a.row_mode == 1) vdiv(acc[q], (float)(d > 1 ? d : 1));
             else if (a.row_mode == 2) vscale(acc[q], a.row_scale[row]);
+            if (a.col_s) vaffine(acc[q], a.col_s + coff[q], a.col_t + coff[q], d > 0);
             if (owns[q]) {
                 if (a.add) vadd(acc[q], *reinterpret_cast<const V*>(a.add + row * a.ldadd + coff[q]));
                 *reinterpret_cast<V*>(a.out + row * a.ldo + coff[q]) = acc[q];
@@ -225,6 +239,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_aggregate_long(const AggArg
                 for (int q = 1; q < LONG_WAVES; ++q) vadd(tot, sh[q * 64 + lane]);
                 if (a.row_mode == 1) vdiv(tot, (float)(len > 1 ? len : 1));
                 else if (a.row_mode == 2) vscale(tot, a.row_scale[row]);
+                if (a.col_s) vaffine(tot, a.col_s + coff, a.col_t + coff, len > 0);
                 if (owns) {
                     if (a.add) vadd(tot, *reinterpret_cast<const V*>(a.add + row * a.ldadd + coff));
                     *reinterpret_cast<V*>(a.out + row * a.ldo + coff) = tot;
@@ -314,7 +329,7 @@ extern "C" int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_
     HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd: null buffer");
     HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd: leading dimension < F");
     HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd: bad row_mode");
-    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, 0};
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, 0, nullptr, nullptr};
     return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream);
 }
 
@@ -334,20 +349,43 @@ extern "C" int hgv_csr_long_rows(const int32_t* rowptr, int64_t n_rows, int thre
 // hgv_agg_fwd for graphs with hubs: rows longer than `threshold` are skipped by the row-per-lane-group kernel; with
 // run_long_pass != 0 a second launch sums the rows listed by hgv_csr_long_rows (same threshold) with one workgroup per
 // row.  run_long_pass = 0 is for callers that know the list is empty.  Every row is written by exactly one of the two.
-extern "C" int hgv_agg_fwd_long(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx,
+static int agg_fwd_long_any(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx,
                                 int F, int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w,
                                 const float* add, int64_t ldadd, float* out, int64_t ldo, int threshold,
                                 const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
-                                hipStream_t stream) {
+                                const float* col_s, const float* col_t, hipStream_t stream) {
     HGV_REQUIRE(n_rows >= 0 && F >= 0, HGV_EINVAL, "agg_fwd_long: negative size");
     if (n_rows == 0 || F == 0) return HGV_OK;
     HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd_long: null buffer");
     HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd_long: leading dimension < F");
     HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd_long: bad row_mode");
     HGV_REQUIRE(threshold > 0 && long_rows && long_count && long_cap > 0, HGV_EINVAL, "agg_fwd_long: bad long-row list");
-    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold};
+    HGV_REQUIRE((col_s == nullptr) == (col_t == nullptr) && (!col_s || (row_mode == 1 && !add && hgv_aligned(col_s, 16) && hgv_aligned(col_t, 16))),
+                HGV_EINVAL, "agg_fwd_affine: column scale and shift come together, 16-byte aligned, with the row mean and no addend");
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold, col_s, col_t};
     return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream, run_long_pass ? long_rows : nullptr, long_count,
                             long_cap);
+}
+
+extern "C" int hgv_agg_fwd_long(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* x, int64_t ldx,
+                                int F, int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w,
+                                const float* add, int64_t ldadd, float* out, int64_t ldo, int threshold,
+                                const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
+                                hipStream_t stream) {
+    return agg_fwd_long_any(rowptr, col, n_rows, x, ldx, F, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold,
+                            long_rows, long_count, long_cap, run_long_pass, nullptr, nullptr, stream);
+}
+
+// hgv_agg_fwd_long (row_mode 1, no addend) over source rows that are handed over un-normalised: x = a * col_s + col_t
+// column by column (col_s / col_t: 4 * ceil(F / 4) floats, 16-byte aligned).  out_i = mean_j(a_j) * col_s + col_t for a row
+// with neighbours, 0 otherwise - the mean aggregation of x without x ever being written.
+extern "C" int hgv_agg_fwd_affine(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* a, int64_t lda, int F,
+                                  const float* col_s, const float* col_t, float* out, int64_t ldo, int threshold,
+                                  const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
+                                  hipStream_t stream) {
+    HGV_REQUIRE(col_s && col_t, HGV_EINVAL, "agg_fwd_affine: null column scale / shift");
+    return agg_fwd_long_any(rowptr, col, n_rows, a, lda, F, 1, nullptr, nullptr, nullptr, nullptr, 0, out, ldo, threshold,
+                            long_rows, long_count, long_cap, run_long_pass, col_s, col_t, stream);
 }
 
 // Backward of the mean/sum aggregation with respect to x: run over the transposed CSR

@@ -33,6 +33,8 @@ struct EpArgs {
     uint64_t seed, offset;
     uint64_t offset2;                // Philox offset of the second noise set (kernels instantiated for two sets)
     const uint64_t* offset_dev;      // optional device word added to offset (advanced once per step under graph replay)
+    int pre;                         // y already holds d = dropout(relu(y)) (written by the producing kernel; without a relu
+                                     // a dropped element is -0.0f, a kept zero +0.0f): nothing is recomputed or regenerated
 };
 
 template <bool VEC>
@@ -97,8 +99,23 @@ __device__ __forceinline__ void chunk_cols(const EpArgs& a, int cp, int (&c)[2])
 }
 
 // d = dropout(relu(y)) for the two chunks of pair cp in one row; yv holds the loaded y values
+__device__ __forceinline__ float keep_of(const EpArgs& a, float v) {
+    // activated input: behind a relu the derivative is zero wherever the value is (dropped or clamped alike); without one
+    // the dropped elements are the negative zeros
+    if (a.relu) return a.scale;
+    return __float_as_uint(v) == 0x80000000u ? 0.f : a.scale;
+}
+
 __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, const float4 (&yv)[2], float4 (&d)[2],
                                          float4* keep_out = nullptr, int set = 0) {
+    if (a.pre) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            d[h] = yv[h];
+            if (keep_out) keep_out[h] = make_float4(keep_of(a, yv[h].x), keep_of(a, yv[h].y), keep_of(a, yv[h].z), keep_of(a, yv[h].w));
+        }
+        return;
+    }
     float4 k[2];
     if (a.mode != 0) keep8(a, row, cp, k, set);
     else k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -251,7 +268,11 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
                                                            float* __restrict__ running_var,
                                                            float* __restrict__ save_mean,
                                                            float* __restrict__ save_rstd,
-                                                           int64_t* __restrict__ num_batches_tracked, int nsets) {
+                                                           int64_t* __restrict__ num_batches_tracked, int nsets,
+                                                           const float* __restrict__ gamma = nullptr,
+                                                           const float* __restrict__ beta = nullptr,
+                                                           float* __restrict__ col_s = nullptr,
+                                                           float* __restrict__ col_t = nullptr) {
     __shared__ double sh[FIN_SL][17];
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += nsets;
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -287,6 +308,7 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
         }
         const double s1 = fin_tree(sh, sl, cl, a1);
         const double s2 = fin_tree(sh, sl, cl, a2);
+        if (sl == 0 && !ok && col_s && c < Hp) col_s[c] = col_t[c] = 0.f;       // pad columns stay zero
         if (sl == 0 && ok) {
             const double mean = pivot + s1 / (double)N;
             double m2 = s2 - s1 * s1 / (double)N;
@@ -294,6 +316,12 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
             const double var = m2 / (double)N;
             save_mean[set * H + c] = (float)mean;
             save_rstd[set * H + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (col_s) {
+                // the normalisation as one multiply-add per element: out = d * s + t with the rounded rstd the backward uses
+                const double sc = (double)(gamma ? gamma[c] : 1.f) * (double)save_rstd[set * H + c];
+                col_s[c] = (float)sc;
+                col_t[c] = (float)((double)(beta ? beta[c] : 0.f) - mean * (double)(float)sc);
+            }
             if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
             if (running_var) {
                 const double unb = N > 1 ? m2 / (double)(N - 1) : var;
@@ -619,6 +647,7 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
     a.mask = mask; a.seed = seed; a.offset = offset; a.offset2 = 0; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
+    a.pre = 0;
     // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread - two rows per
     // thread for small matrices, where the launch is as long as its longest workgroup (4 416 x 138: 4 % of a captured step
     // against 4 rows; one row per thread is slower again at width 256)
@@ -652,7 +681,8 @@ int bn_act_fwd_launch(const EpArgs& a, int nb, const float* gamma, const float* 
     else if (vec) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
     else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
     hipLaunchKernelGGL(k_ep_stats_finalize, dim3((a.H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
-                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, nsets);
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, nsets,
+                       nullptr, nullptr, nullptr, nullptr);
     NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo, out2};
     if (nsets == 2) hipLaunchKernelGGL((k_ep_apply<true, 2>), dim3(nb), dim3(256), 0, stream, a, n);
     else if (vec) hipLaunchKernelGGL((k_ep_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, n);
@@ -775,6 +805,120 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int6
     if (vec) hipLaunchKernelGGL((k_ep_bwd_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, b);
     else hipLaunchKernelGGL((k_ep_bwd_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd");
+    return HGV_OK;
+}
+
+// ---- levels whose activation was applied by the producing kernel -------------------------------------------------------
+// The projection that feeds a level can apply relu -> dropout itself while it stores its tile (hgv_gemm_nt16h_act), so the
+// matrix between the two holds d = dropout(relu(y)) instead of y.  Then the level needs only the column statistics of d:
+// the normalisation out = d * col_s + col_t (col_s = gamma * rstd, col_t = beta - mean * col_s) is handed to the
+// consumers as two vectors - a following projection folds them into its weights (hgv_pack16h_weights_affine), a mean
+// aggregation applies them to its finished rows (hgv_agg_fwd_affine) - and `out` is never written
+// (gvae/gvae_skipcon.py:105-107 -> :110, :124-130: Dropout / BatchNorm1d outputs consumed by the next SAGEConv / Linear).
+// hgv_bn_stats: statistics (save_mean / save_rstd), running-buffer update and col_s / col_t (4 * ceil(H / 4) floats each,
+// pad columns zero) of the activated matrix d [N, H].
+extern "C" int hgv_bn_stats(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
+                            float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                            float* save_mean, float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes,
+                            hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d, ldd, N, H, 0, 0.f, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(save_mean && save_rstd && col_s && col_t && ws, HGV_EINVAL, "bn_stats: null buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_stats: workspace too small or misaligned");
+    a.pre = 1;
+    const int Hp = a.CH * 4;
+    float* partial = (float*)ws;
+    if (vec4_ok(d, ldd, Hp)) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 1,
+                       gamma, beta, col_s, col_t);
+    HGV_CHECK_LAUNCH("bn_stats");
+    return HGV_OK;
+}
+
+// out = (d - mean) * rstd * gamma + beta for a consumer that needs the normalised matrix after all (same arithmetic as
+// the second pass of hgv_bn_act_fwd).
+extern "C" int hgv_bn_apply(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta,
+                            const float* save_mean, const float* save_rstd, float* out, int64_t ldo, hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d, ldd, N, H, 0, 0.f, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(out && ldo >= H && save_mean && save_rstd, HGV_EINVAL, "bn_apply: null/short buffer");
+    a.pre = 1;
+    const int Hp = a.CH * 4;
+    NormArgs n{save_mean, save_rstd, 0, 0.f, gamma, beta, out, ldo, nullptr};
+    if (vec4_ok(d, ldd, Hp) && vec4_ok(out, ldo, Hp)) hipLaunchKernelGGL((k_ep_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, n);
+    else hipLaunchKernelGGL((k_ep_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, n);
+    HGV_CHECK_LAUNCH("bn_apply");
+    return HGV_OK;
+}
+
+// Backward of such a level: hgv_bn_act_bwd with the activated matrix d in place of y.  dy is the gradient with respect to
+// the projection's output BEFORE its activation (the producing operator is linear from there on); p as in the forward.
+extern "C" int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* d, int64_t ldd,
+                                  int64_t N, int H, int relu, float p, const float* gamma, const float* save_mean,
+                                  const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, int accumulate,
+                                  void* ws, size_t ws_bytes, hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d, ldd, N, H, relu, p, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(g && ldg >= H && dy && lddy >= H && save_mean && save_rstd && ws && (!g2 || ldg2 >= H), HGV_EINVAL, "bn_act_bwd_pre: null/short buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd_pre: workspace too small or misaligned");
+    a.pre = 1; a.mode = 0;
+    const int Hp = a.CH * 4;
+    float* partial = (float*)ws;
+    float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, nullptr, 0, nullptr, 0};
+    const bool vec = vec4_ok(d, ldd, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(dy, lddy, Hp);
+    if (vec) hipLaunchKernelGGL((k_ep_bwd_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+    else hipLaunchKernelGGL((k_ep_bwd_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+    hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 1);
+    if (vec) hipLaunchKernelGGL((k_ep_bwd_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, b);
+    else hipLaunchKernelGGL((k_ep_bwd_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, b);
+    HGV_CHECK_LAUNCH("bn_act_bwd_pre");
+    return HGV_OK;
+}
+
+// Weight-gradient finish for operands that were handed over un-normalised.  With x = a * s + t column by column,
+//   G^T x = (G^T a) diag(s) + colsum(G) t^T:
+// dst[n,k] (+)= raw[n,k] * s[k] + colsum[n] * t[k]   (s / t null: dst (+)= raw).  Up to three jobs per launch (the two
+// halves of a K-concatenated weight and the bias vector as an N x 1 matrix).
+namespace {
+struct FinishJob { float* dst; int64_t lddst; const float* raw; int64_t ldraw; int N, K; const float* s; const float* t; const float* colsum; };
+struct FinishArgs { FinishJob job[3]; int njobs; int accumulate; };
+__global__ __launch_bounds__(256) void k_wgrad_finish(const FinishArgs f) {
+    const FinishJob& j = f.job[blockIdx.y];
+    const int64_t total = (int64_t)j.N * j.K;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int n = (int)(e / j.K), k = (int)(e - (int64_t)n * j.K);
+        float v = j.raw[(int64_t)n * j.ldraw + k];
+        if (j.s) v = __fmaf_rn(v, j.s[k], j.colsum[n] * j.t[k]);
+        float* d = j.dst + (int64_t)n * j.lddst + k;
+        *d = f.accumulate ? *d + v : v;
+    }
+}
+}  // namespace
+
+extern "C" int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* lddst, const float* const* raw, const int64_t* ldraw,
+                                const int* N, const int* K, const float* const* s, const float* const* t,
+                                const float* const* colsum, int accumulate, hipStream_t stream) {
+    HGV_REQUIRE(njobs >= 1 && njobs <= 3 && dst && lddst && raw && ldraw && N && K && s && t && colsum, HGV_EINVAL,
+                "wgrad_finish: 1..3 jobs and non-null arrays expected");
+    FinishArgs f{};
+    f.njobs = njobs; f.accumulate = accumulate;
+    int64_t most = 0;
+    for (int q = 0; q < njobs; ++q) {
+        HGV_REQUIRE(dst[q] && raw[q] && N[q] > 0 && K[q] > 0 && lddst[q] >= K[q] && ldraw[q] >= K[q], HGV_EINVAL, "wgrad_finish: bad job %d", q);
+        HGV_REQUIRE((s[q] == nullptr) == (t[q] == nullptr) && (!s[q] || colsum[q]), HGV_EINVAL, "wgrad_finish: job %d needs s, t and colsum together", q);
+        f.job[q] = FinishJob{dst[q], lddst[q], raw[q], ldraw[q], N[q], K[q], s[q], t[q], colsum[q]};
+        most = (int64_t)N[q] * K[q] > most ? (int64_t)N[q] * K[q] : most;
+    }
+    int64_t blocks = hgv_cdiv(most, 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_wgrad_finish, dim3((unsigned)blocks, (unsigned)njobs), dim3(256), 0, stream, f);
+    HGV_CHECK_LAUNCH("wgrad_finish");
     return HGV_OK;
 }
 

@@ -79,6 +79,19 @@ def _agg_launch_raw(csr, n_rows, x, F, row_mode, row_scale, edge_w, nbr_w, add, 
               lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0, _lib.stream())
 
 
+def _agg_affine_launch(csr, n_rows, d, F, col_s, col_t, out):
+    """Mean aggregation of x = d * col_s + col_t (never written) over ``csr``: see hgv_agg_fwd_affine."""
+    ev = _probe.add("agg", (n_rows, F, csr.col.numel())) if _probe is not None else None
+    if ev:
+        ev[0].record()
+    lr = csr.long_rows(n_rows)
+    _lib.call("hgv_agg_fwd_affine", csr.rowptr.data_ptr(), csr.col.data_ptr(), n_rows, d.data_ptr(), ld_of(d), F,
+              col_s.data_ptr(), col_t.data_ptr(), out.data_ptr(), ld_of(out), lr.threshold, lr.rows.data_ptr(),
+              lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0, _lib.stream())
+    if ev:
+        ev[1].record()
+
+
 class _Aggregate(torch.autograd.Function):
     """out_i = (mean | sum) over in-neighbours j of x_j."""
 
@@ -102,6 +115,7 @@ class _Aggregate(torch.autograd.Function):
 
 
 def aggregate(x: torch.Tensor, graph: Graph, mean: bool = True) -> torch.Tensor:
+    x = plain(x)
     if x.size(0) != graph.num_nodes:
         raise _lib.HgvError(f"x has {x.size(0)} rows but the graph has {graph.num_nodes} nodes")
     return _Aggregate.apply(x, graph, mean)
@@ -128,6 +142,262 @@ class _WeightedAggregate(torch.autograd.Function):
         gx = new_padded(graph.num_nodes, g.size(1), g.device, zero_pad=False)
         _agg_launch(graph.by_src, graph.num_nodes, g, g.size(1), 0, None, w_t, None, None, gx)
         return gx, None, None
+
+
+
+# --------------------------------------------------------------------------------------
+# levels whose normalisation is deferred to their consumers
+# --------------------------------------------------------------------------------------
+# A level is  y = projection(...) -> relu? -> dropout -> batch norm  and its output feeds further projections / mean
+# aggregations.  Inside :func:`deferred_levels` (the loss functions of the train loops enter it) the projection applies
+# relu -> dropout while it stores its tile, the level takes the column statistics of that matrix d and hands out a
+# :class:`Deferred` - d plus the two vectors of  out = d * s + t  - and the consumers fold s / t into their weights
+# (``_image_affine``), apply them to finished aggregation rows, and correct their weight gradients (``_wgrad``): the
+# normalised matrix is never written or read.  HGVAE_DEFER=0 switches the mechanism off (A/B measurements).
+_DEFER_ENABLED = os.environ.get("HGVAE_DEFER", "1") != "0"
+DEFER_MIN_P = 0.2        # folding s / t into the weights turns  (d - mean) * rstd  into a difference of two sums; dropout
+                         # with probability p bounds |mean| / std of d by sqrt((1 - p) / p), so nothing cancels for p >= 0.2
+_defer = False
+
+
+def set_deferred_levels(enabled: bool) -> None:
+    global _DEFER_ENABLED
+    _DEFER_ENABLED = bool(enabled)
+
+
+@contextlib.contextmanager
+def deferred_levels(enabled: bool = True):
+    global _defer
+    prev, _defer = _defer, bool(enabled) and _DEFER_ENABLED and _projection == "f16x3"
+    try:
+        yield
+    finally:
+        _defer = prev
+
+
+class ActSpec:
+    """relu? -> dropout(p) with its noise, for a projection to apply while it stores its output."""
+    __slots__ = ("relu", "p", "mask", "seed", "offset", "ctr")
+
+    def __init__(self, relu, p, mask, seed, offset, ctr):
+        self.relu, self.p, self.mask, self.seed, self.offset, self.ctr = bool(relu), float(p), mask, seed, offset, ctr
+
+
+class Deferred:
+    """Output of a level, kept as d = dropout(relu(y)) [N, H] and the column vectors s, t of  out = d * s + t.
+
+    ``d`` is connected to the autograd graph; by convention the gradient that flows back into it is the gradient with
+    respect to ``out`` (the consumers in this module compute exactly that).  ``tensor()`` writes ``out`` for a consumer
+    that needs the matrix."""
+    __slots__ = ("d", "s", "t", "mean", "rstd", "gamma", "beta", "_out")
+
+    def __init__(self, d, s, t, mean, rstd, gamma, beta):
+        self.d, self.s, self.t, self.mean, self.rstd, self.gamma, self.beta = d, s, t, mean, rstd, gamma, beta
+        self._out = None
+
+    @property
+    def shape(self):
+        return self.d.shape
+
+    @property
+    def device(self):
+        return self.d.device
+
+    @property
+    def requires_grad(self):
+        return self.d.requires_grad
+
+    def size(self, dim=None):
+        return self.d.size() if dim is None else self.d.size(dim)
+
+    def dim(self):
+        return self.d.dim()
+
+    def tensor(self) -> torch.Tensor:
+        if self._out is None:
+            self._out = _Materialize.apply(self.d, self.mean, self.rstd, self.gamma, self.beta)
+        return self._out
+
+
+class _Materialize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, mean, rstd, gamma, beta):
+        out = new_padded(d.size(0), d.size(1), d.device, zero_pad=not is_vec4(d))
+        _lib.call("hgv_bn_apply", d.data_ptr(), ld_of(d), d.size(0), d.size(1), _lib.ptr(gamma), _lib.ptr(beta),
+                  mean.data_ptr(), rstd.data_ptr(), out.data_ptr(), ld_of(out), _lib.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None, None          # the gradient with respect to `out` is what flows into d
+
+
+def plain(x):
+    """``x`` as an ordinary tensor (writes the normalised matrix of a :class:`Deferred`)."""
+    return x.tensor() if isinstance(x, Deferred) else x
+
+
+def _affine_ok(n: int, k1: int, k2: int) -> bool:
+    """A consumer with an n x (k1 + k2) weight can fold column scales into its image (the scaled-fp16 kernels take it)."""
+    return _projection == "f16x3" and _split_image_floats(n, k1, k2, "f16x3") > 0
+
+
+def _act_ok(n: int, k1: int, k2: int) -> bool:
+    return _projection == "f16x3" and bool(_lib.load().hgv_gemm_nt16h_act_supported(n, k1, k2))
+
+
+def _image_affine(wa, aff_a, wb, aff_b, bias):
+    """(scaled-fp16 image of [wa diag(s_a) | wb diag(s_b)], bias + wa t_a + wb t_b); ``aff`` = (s, t) or None."""
+    n, k1 = wa.shape
+    k2 = wb.size(1) if wb is not None else 0
+    buf = torch.empty(_split_image_floats(n, k1, k2, "f16x3"), dtype=torch.float32, device=wa.device)
+    bias_out = torch.empty(n, dtype=torch.float32, device=wa.device)
+    sa, ta = aff_a if aff_a is not None else (None, None)
+    sb, tb = aff_b if aff_b is not None else (None, None)
+    _lib.call("hgv_pack16h_weights_affine", wa.data_ptr(), wa.stride(0), wa.stride(1), k1, _lib.ptr(sa), _lib.ptr(ta),
+              _lib.ptr(wb), wb.stride(0) if wb is not None else 0, wb.stride(1) if wb is not None else 0, k2,
+              _lib.ptr(sb), _lib.ptr(tb), n, _lib.ptr(bias), bias_out.data_ptr(), buf.data_ptr(), _lib.stream())
+    return _Image("f16x3", buf), bias_out
+
+
+def _wgrad_finish(jobs, colsum, accumulate: bool) -> None:
+    """dst (+)= raw * s + colsum t^T for up to three ``(dst, raw, (s, t) or None)`` jobs in one launch."""
+    nj = len(jobs)
+    vp_t, i64_t, i32_t = _ctypes_arrays(nj)
+    D, R, S, T, CS = vp_t(), vp_t(), vp_t(), vp_t(), vp_t()
+    ldd, ldr = i64_t(), i64_t()
+    N, K = i32_t(), i32_t()
+    for q, (d, r, aff) in enumerate(jobs):
+        if tuple(d.shape) != tuple(r.shape) or (d.size(1) > 1 and (d.stride(1) != 1 or r.stride(1) != 1)):
+            raise _lib.HgvError(f"weight-gradient finish: {tuple(d.shape)} / {d.stride()} from {tuple(r.shape)} / {r.stride()}")
+        D[q], R[q], ldd[q], ldr[q], N[q], K[q] = d.data_ptr(), r.data_ptr(), max(d.stride(0), d.size(1)), max(r.stride(0), r.size(1)), r.size(0), r.size(1)
+        if aff is not None:
+            S[q], T[q], CS[q] = aff[0].data_ptr(), aff[1].data_ptr(), colsum.data_ptr()
+    _lib.call("hgv_wgrad_finish", nj, D, ldd, R, ldr, N, K, S, T, CS, 1 if accumulate else 0, _lib.stream())
+
+
+def _wgrad(g, ops, bias, want_bias: bool):
+    """Weight (and bias) gradients of  y = sum_i x_i @ w_i^T + bias  for one or two operands.
+
+    ``ops`` = [(x, w, aff, want)]: ``x`` the stored operand, ``aff`` = (s, t) when the operand the product really saw was
+    x * s + t column by column (then G^T (x s + t) = (G^T x) diag(s) + colsum(G) t^T is formed from the raw product).
+    Returns ([gw_i ...], gb) for autograd with None where a gradient was added straight into ``.grad`` or not wanted."""
+    live = [(x, w, aff) for (x, w, aff, want) in ops if want]
+    if not live:
+        if want_bias:
+            _, gb = _gemm_tn(g, ops[0][0], True)
+            return [None] * len(ops), gb
+        return [None] * len(ops), None
+    if all(aff is None for (_, _, aff) in live):
+        if len(live) == 2:
+            ga, gb_, gbias = _weight_grad2(g, live[0][0], live[0][1], live[1][0], live[1][1], bias, want_bias)
+            res = [ga, gb_]
+        else:
+            ga, gbias = _weight_grad(g, live[0][0], live[0][1], bias, want_bias)
+            res = [ga]
+    else:
+        if len(live) == 2:
+            ra, rb, colsum = _gemm_tn2(g, live[0][0], live[1][0], True)
+            raws = [ra, rb]
+        else:
+            ra, colsum = _gemm_tn(g, live[0][0], True)
+            raws = [ra]
+        bufs = [_grad_buffer(w) for (_, w, _) in live]
+        bbuf = _grad_buffer(bias) if want_bias else None
+        direct = all(b is not None for b in bufs) and (not want_bias or bbuf is not None)
+        dsts = bufs if direct else [torch.empty(w.shape, dtype=torch.float32, device=g.device) for (_, w, _) in live]
+        jobs = [(d, r, aff) for d, r, (_, _, aff) in zip(dsts, raws, live)]
+        gbias = None
+        if want_bias:
+            gbias = bbuf if direct else torch.empty_like(colsum)
+            jobs.append((gbias.view(-1, 1), colsum.view(-1, 1), None))
+        _wgrad_finish(jobs, colsum, accumulate=direct)
+        res = [None] * len(live) if direct else dsts
+        gbias = None if direct else gbias
+    out, it = [], iter(res)
+    for (_, _, _, want) in ops:
+        out.append(next(it) if want else None)
+    return out, gbias
+
+
+class _BnStats(torch.autograd.Function):
+    """Column statistics of an activated matrix d (see :class:`Deferred`): returns one or two handles on d and the
+    vectors [s | t], mean, rstd; the backward pass is that of relu? -> dropout -> batch norm read off d."""
+
+    @staticmethod
+    def forward(ctx, d, gamma, beta, running_mean, running_var, relu, p, eps, momentum, tracked, fork):
+        n, h = d.shape
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, h), d.device, "bn")
+        hp = (h + 3) // 4 * 4
+        st = torch.empty(2, hp, dtype=torch.float32, device=d.device)
+        save_mean = torch.empty(h, dtype=torch.float32, device=d.device)
+        save_rstd = torch.empty(h, dtype=torch.float32, device=d.device)
+        _lib.call("hgv_bn_stats", d.data_ptr(), ld_of(d), n, h, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+                  _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked), save_mean.data_ptr(),
+                  save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        ctx.cfg = (bool(relu), float(p))
+        ctx.save_for_backward(d, gamma, save_mean, save_rstd, beta)
+        ctx.mark_non_differentiable(st, save_mean, save_rstd)
+        ctx.set_materialize_grads(False)
+        if fork:
+            return d.view_as(d), d.view_as(d), st, save_mean, save_rstd
+        return d.view_as(d), st, save_mean, save_rstd
+
+    @staticmethod
+    def backward(ctx, *grads):
+        d, gamma, save_mean, save_rstd, beta = ctx.saved_tensors
+        relu, p = ctx.cfg
+        g, g2 = (grads[0], grads[1]) if len(grads) == 5 else (grads[0], None)
+        if g is None:
+            g, g2 = g2, None
+        if g is None:
+            return (None,) * 11
+        n, h = d.shape
+        g = rowmajor(g)
+        g2 = rowmajor(g2) if g2 is not None else None
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, h), d.device, "bn")
+        vec = is_vec4(d) and is_vec4(g) and (g2 is None or is_vec4(g2))
+        dy = new_padded(n, h, d.device, zero_pad=not vec)
+        need = ctx.needs_input_grad
+        gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
+        direct = gbuf is not None and bbuf is not None
+        dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
+        dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
+        _lib.call("hgv_bn_act_bwd_pre", g.data_ptr(), ld_of(g), _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, d.data_ptr(),
+                  ld_of(d), n, h, int(relu), float(p), _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
+                  dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(),
+                  ws.numel(), _lib.stream())
+        if direct:
+            dgamma = dbeta = None
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 8
+
+
+def bn_level(make_y, n_rows: int, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
+    """One level: ``make_y(act)`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` is called once, with an
+    :class:`ActSpec` when the level may be deferred (the producer applies it and tags its output) or None; the result is
+    a tensor, or a :class:`Deferred` (a pair of either with ``fork``)."""
+    if _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P and n_rows >= 2:
+        dev = bn.weight.device if bn.weight is not None else bn.running_mean.device
+        mask, seed, offset, ctr = current_noise().dropout((n_rows, bn.num_features), dev)
+        act = ActSpec(relu, p, mask, seed, offset, ctr)
+        y = make_y(act)
+        if getattr(y, "_hgv_act", None) is act:
+            momentum = bn.momentum if bn.momentum is not None else 0.1
+            rm, rv, tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
+            if on_branch_stream():         # see bn_act: the trunk may be updating the running statistics right now
+                stand_in = torch.zeros(2, y.size(1), dtype=torch.float32, device=y.device)
+                _branch_updates.append((bn, stand_in, momentum))
+                rm, rv, tracked = stand_in[0], stand_in[1], None
+            outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, bn.eps, momentum, tracked, fork)
+            st, mean, rstd = outs[-3], outs[-2], outs[-1]
+            made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias) for h in outs[:-3]]
+            return (made[0], made[1]) if fork else made[0]
+        return bn_act(plain(y), bn, relu, p, training, fork=fork, noise=(mask, seed, offset, ctr))
+    return bn_act(plain(make_y(None)), bn, relu, p, training, fork=fork)
 
 
 # --------------------------------------------------------------------------------------
@@ -420,9 +690,10 @@ def _assert_zero_pads(*operands) -> None:
             raise _lib.HgvError(f"projection operand of shape {tuple(t.shape)} (leading dimension {ld_of(t)}) has non-zero pad columns")
 
 
-def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
+def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, act: Optional["ActSpec"] = None) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
-    xa / xb must already be in the padded layout."""
+    xa / xb must already be in the padded layout.  With ``act`` (callers check :func:`_act_ok` first) the kernel stores
+    dropout(relu(out)) and the result carries the spec as ``_hgv_act``."""
     m = xa.size(0)
     if _CHECK_PADS:
         _assert_zero_pads(xa, xb)
@@ -430,7 +701,14 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     if ev:
         ev[0].record()
-    if img.kind == "auto":
+    if act is not None:
+        if img.kind != "f16x3":
+            raise _lib.HgvError("a fused activation needs the scaled-fp16 projection kernels")
+        _lib.call("hgv_gemm_nt16h_act", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
+                  ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
+                  _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), int(act.relu), float(act.p), _lib.ptr(act.mask),
+                  act.seed, act.offset, act.ctr, _lib.stream())
+    elif img.kind == "auto":
         # one pass over the operands decides on the device; both products are enqueued and exactly one of them runs
         flag = _workspace(256, xa.device, "range_flag")
         a2 = (_lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0)
@@ -646,10 +924,12 @@ def _weight_grad2(g, xa, wa, xb, wb, bias=None, want_bias: bool = False):
 
 
 class _DualLinear(torch.autograd.Function):
-    """y = xa @ Wa^T + xb @ Wb^T + bias on the fp32-MFMA kernels (xb / Wb / bias optional)."""
+    """y = xa @ Wa^T + xb @ Wb^T + bias on the matrix-core kernels (xb / Wb / bias optional).  ``aff_a`` / ``aff_b``: the
+    (s, t) vectors of an operand that arrives un-normalised (see :class:`Deferred`); ``act``: relu -> dropout to apply to
+    the stored result (see :func:`bn_level`)."""
 
     @staticmethod
-    def forward(ctx, xa, wa, xb, wb, bias):
+    def forward(ctx, xa, wa, xb, wb, bias, aff_a=None, aff_b=None, act=None):
         _lib.require_cuda(xa, wa)
         if wa.size(0) > MAX_GEMM_N or wa.size(1) > MAX_GEMM_N or (wb is not None and wb.size(1) > MAX_GEMM_N):
             raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported "
@@ -657,11 +937,17 @@ class _DualLinear(torch.autograd.Function):
         xa = as_padded(xa)
         xb = as_padded(xb) if xb is not None else None
         need = ctx.needs_input_grad
-        fwd, ctx.pat, ctx.pbt = _images((wa, wb if xb is not None else None, False),
+        folded = aff_a is not None or aff_b is not None
+        fwd, ctx.pat, ctx.pbt = _images(None if folded else (wa, wb if xb is not None else None, False),
                                         (wa, None, True) if need[0] else None,
                                         (wb, None, True) if xb is not None and need[2] else None)
-        y = _gemm_nt(xa, fwd, xb, bias, wa.size(0))
+        if folded:
+            fwd, bias_f = _image_affine(wa, aff_a, wb if xb is not None else None, aff_b, bias)
+        else:
+            bias_f = bias
+        y = _gemm_nt(xa, fwd, xb, bias_f, wa.size(0), act)
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
+        ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, wa, xb, wb, bias)
         return y
 
@@ -670,32 +956,28 @@ class _DualLinear(torch.autograd.Function):
         xa, wa, xb, wb, bias = ctx.saved_tensors
         g = as_padded(g)
         need = ctx.needs_input_grad
-        gxa = gwa = gxb = gwb = gb = None
+        gxa = gxb = None
         want_bias = ctx.has_bias and need[4]
         if need[0]:
             gxa = _gemm_nt(g, ctx.pat, None, None, wa.size(1))
-        if ctx.has_b and need[1] and need[3]:
-            gwa, gwb, gb = _weight_grad2(g, xa, wa, xb, wb, bias, want_bias)
-        else:
-            if need[1]:
-                gwa, gb = _weight_grad(g, xa, wa, bias, want_bias)
-            elif want_bias:
-                _, gb = _gemm_tn(g, xa, True)
-            if ctx.has_b and need[3]:
-                gwb, _ = _weight_grad(g, xb, wb)
+        ops = [(xa, wa, ctx.aff_a, need[1])]
+        if ctx.has_b:
+            ops.append((xb, wb, ctx.aff_b, need[3]))
+        gws, gb = _wgrad(g, ops, bias, want_bias)
+        gwa, gwb = gws[0], (gws[1] if ctx.has_b else None)
         if ctx.has_b and need[2]:
             gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
-        return gxa, gwa, gxb, gwb, gb
+        return gxa, gwa, gxb, gwb, gb, None, None, None
 
 
 class _ConcatLinear(torch.autograd.Function):
     """y = [xa | xb] @ W^T + bias for one weight W [n_out, Ka + Kb] (a decoder level fed by the
     concatenation of the running activation and a skip tensor, gvae/gvae_skipcon.py:92-100).  The
     concatenation is never built, and both halves of the weight gradient are written straight into
-    one [n_out, Ka + Kb] matrix."""
+    one [n_out, Ka + Kb] matrix.  ``aff_a`` / ``aff_b`` / ``act`` as in :class:`_DualLinear`."""
 
     @staticmethod
-    def forward(ctx, xa, xb, w, bias):
+    def forward(ctx, xa, xb, w, bias, aff_a=None, aff_b=None, act=None):
         _lib.require_cuda(xa, xb, w)
         ka, kb = xa.size(1), xb.size(1)
         if w.size(1) != ka + kb:
@@ -705,10 +987,16 @@ class _ConcatLinear(torch.autograd.Function):
         xa, xb = as_padded(xa), as_padded(xb)
         need = ctx.needs_input_grad
         wa, wb = w[:, :ka], w[:, ka:]
-        fwd, ctx.pat, ctx.pbt = _images((wa, wb, False), (wa, None, True) if need[0] else None,
+        folded = aff_a is not None or aff_b is not None
+        fwd, ctx.pat, ctx.pbt = _images(None if folded else (wa, wb, False), (wa, None, True) if need[0] else None,
                                         (wb, None, True) if need[1] else None)
-        y = _gemm_nt(xa, fwd, xb, bias, w.size(0))
+        if folded:
+            fwd, bias_f = _image_affine(wa, aff_a, wb, aff_b, bias)
+        else:
+            bias_f = bias
+        y = _gemm_nt(xa, fwd, xb, bias_f, w.size(0), act)
         ctx.has_bias = bias is not None
+        ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, xb, w, bias)
         return y
 
@@ -727,18 +1015,49 @@ class _ConcatLinear(torch.autograd.Function):
         if need[2] or want_bias:
             wbuf = _grad_buffer(w) if need[2] else None
             bbuf = _grad_buffer(bias) if want_bias else None
-            if wbuf is not None and (not want_bias or bbuf is not None):     # add both halves into w.grad
-                _gemm_tn2(g, xa, xb, want_bias, wbuf[:, :ka], wbuf[:, ka:], bbuf, accumulate=True)
+            direct = wbuf is not None and (not want_bias or bbuf is not None)
+            if ctx.aff_a is None and ctx.aff_b is None:
+                if direct:                                      # add both halves into w.grad
+                    _gemm_tn2(g, xa, xb, want_bias, wbuf[:, :ka], wbuf[:, ka:], bbuf, accumulate=True)
+                else:
+                    gw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                    _, _, gb = _gemm_tn2(g, xa, xb, want_bias, gw[:, :ka], gw[:, ka:])
+                    if not need[2]:
+                        gw = None
             else:
-                gw = torch.empty_like(w, memory_format=torch.contiguous_format)
-                _, _, gb = _gemm_tn2(g, xa, xb, want_bias, gw[:, :ka], gw[:, ka:])
-                if not need[2]:
+                # raw products with the stored operands, then  (G^T d) diag(s) + colsum(G) t^T  per half
+                ra, rb, colsum = _gemm_tn2(g, xa, xb, True)
+                if not direct:
+                    gw = torch.empty_like(w, memory_format=torch.contiguous_format)
+                    gb = torch.empty_like(colsum) if want_bias else None
+                dst = wbuf if direct else gw
+                jobs = [(dst[:, :ka], ra, ctx.aff_a), (dst[:, ka:], rb, ctx.aff_b)]
+                if want_bias:
+                    jobs.append(((bbuf if direct else gb).view(-1, 1), colsum.view(-1, 1), None))
+                _wgrad_finish(jobs, colsum, accumulate=direct)
+                if direct or not need[2]:
                     gw = None
-        return gxa, gxb, gw, gb
+                if direct:
+                    gb = None
+        return gxa, gxb, gw, gb, None, None, None
 
 
-def concat_linear(xa, xb, w, bias=None):
-    return _ConcatLinear.apply(xa, xb, w, bias)
+def _unwrap(x, ok: bool):
+    """(stored operand, (s, t) or None) of a projection input; a :class:`Deferred` the projection cannot fold is written out."""
+    if isinstance(x, Deferred):
+        return (x.d, (x.s, x.t)) if ok else (x.tensor(), None)
+    return x, None
+
+
+def concat_linear(xa, xb, w, bias=None, act=None):
+    n, ka, kb = w.size(0), xa.size(1), xb.size(1)
+    ok = _affine_ok(n, ka, kb)
+    (xa, aff_a), (xb, aff_b) = _unwrap(xa, ok), _unwrap(xb, ok)
+    use_act = act if act is not None and _act_ok(n, ka, kb) else None
+    y = _ConcatLinear.apply(xa, xb, w, bias, aff_a, aff_b, use_act)
+    if use_act is not None:
+        y._hgv_act = use_act
+    return y
 
 
 class _SageConv(torch.autograd.Function):
@@ -752,7 +1071,7 @@ class _SageConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, wl, bl, wr, graph: Graph, mean: bool):
+    def forward(ctx, x, wl, bl, wr, graph: Graph, mean: bool, aff=None, act=None):
         _lib.require_cuda(x, wl, wr)
         n_out, n_in = wl.shape
         if max(n_out, n_in) > MAX_GEMM_N:
@@ -762,26 +1081,37 @@ class _SageConv(torch.autograd.Function):
         first = n_out < n_in and 2 * n_out <= MAX_GEMM_N
         gi = ctx.needs_input_grad[0]
         ctx.pt = ctx.plt = ctx.prt = None
+        # aff = (s, t): x holds d of a deferred level and the operand meant is d * s + t (mean aggregation only)
         if first:
             bias2 = torch.cat([torch.zeros_like(bl), bl]) if bl is not None else None
-            stacked, ctx.pt = _images((torch.cat([wl, wr]), None, False), (wl, wr, True) if gi else None)   # gx = gt wl + g wr
+            stacked_w = torch.cat([wl, wr])
+            stacked, ctx.pt = _images(None if aff is not None else (stacked_w, None, False), (wl, wr, True) if gi else None)   # gx = gt wl + g wr
+            if aff is not None:
+                stacked, bias2 = _image_affine(stacked_w, aff, None, None, bias2)
             tr = _gemm_nt(x, stacked, None, bias2, 2 * n_out)
             y = new_padded(n, n_out, x.device)
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
             ctx.save_for_backward(x, wl, wr, bl)
         else:
             agg = new_padded(n, n_in, x.device, zero_pad=False)
-            _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
+            if aff is not None:
+                _agg_affine_launch(graph.by_dst, n, x, n_in, aff[0], aff[1], agg)      # the aggregate of d * s + t itself
+            else:
+                _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
             # Input gradient: aggregate the output gradient first when that is not the wider side
             # (gx = aggT(g) wl + g wr: one K-concatenated product), else project first (two products,
             # the add fused into the aggregation).
+            fwd_spec = None if aff is not None else (wl, wr, False)
             if gi and n_out <= n_in:
-                fwd, ctx.pt = _images((wl, wr, False), (wl, wr, True))
+                fwd, ctx.pt = _images(fwd_spec, (wl, wr, True))
             else:
-                fwd, ctx.plt, ctx.prt = _images((wl, wr, False), (wl, None, True) if gi else None, (wr, None, True) if gi else None)
-            y = _gemm_nt(agg, fwd, x, bl, n_out)
+                fwd, ctx.plt, ctx.prt = _images(fwd_spec, (wl, None, True) if gi else None, (wr, None, True) if gi else None)
+            bias_f = bl
+            if aff is not None:
+                fwd, bias_f = _image_affine(wl, None, wr, aff, bl)         # [wl | wr diag(s)], bl + wr t
+            y = _gemm_nt(agg, fwd, x, bias_f, n_out, act)
             ctx.save_for_backward(x, wl, wr, bl, agg)
-        ctx.graph, ctx.mean, ctx.first, ctx.has_bias = graph, mean, first, bl is not None
+        ctx.graph, ctx.mean, ctx.first, ctx.has_bias, ctx.aff = graph, mean, first, bl is not None, aff
         return y
 
     @staticmethod
@@ -798,18 +1128,15 @@ class _SageConv(torch.autograd.Function):
             n_out, n_in = wl.shape
             gt = new_padded(n, n_out, g.device, zero_pad=False)      # gradient of the aggregated half
             _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
-            gwl, _ = _weight_grad(gt, x, wl)
-            gwr, gb = _weight_grad(g, x, wr, bl, want_bias)
+            (gwl,), _ = _wgrad(gt, [(x, wl, ctx.aff, need[1])], None, False)
+            (gwr,), gb = _wgrad(g, [(x, wr, ctx.aff, need[3])], bl, want_bias)
             if need[0]:
                 gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
-            if need[1] and need[3]:
-                gwl, gwr, gb = _weight_grad2(g, agg, wl, x, wr, bl, want_bias)
-            else:
-                gwl, gb = _weight_grad(g, agg, wl, bl, want_bias)
-                gwr, _ = _weight_grad(g, x, wr)
+            # agg is the aggregate of the normalised operand itself: only the root operand x may be a stored d
+            (gwl, gwr), gb = _wgrad(g, [(agg, wl, None, need[1]), (x, wr, ctx.aff, need[3])], bl, want_bias)
             if need[0] and ctx.pt is not None:
                 gt = new_padded(n, n_out, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
@@ -819,7 +1146,7 @@ class _SageConv(torch.autograd.Function):
                 gr = _gemm_nt(g, ctx.prt, None, None, n_in)
                 gx = new_padded(n, n_in, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, t, n_in, 0, None, None, inv, gr, gx)
-        return gx, gwl, gb, gwr, None, None
+        return gx, gwl, gb, gwr, None, None, None, None
 
 
 class _Fork(torch.autograd.Function):
@@ -845,19 +1172,35 @@ class _Fork(torch.autograd.Function):
 
 def fork(x: torch.Tensor):
     """(x, x) for a tensor with two consumers; see :class:`_Fork`."""
+    x = plain(x)
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
     return _Fork.apply(x)
 
 
-def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True):
+def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True, act=None):
     if x.size(0) != graph.num_nodes:
         raise _lib.HgvError(f"x has {x.size(0)} rows but the graph has {graph.num_nodes} nodes")
-    return _SageConv.apply(x, wl, bl, wr, graph, mean)
+    n_out, n_in = wl.shape
+    first = n_out < n_in and 2 * n_out <= MAX_GEMM_N
+    ok = mean and (_affine_ok(2 * n_out, n_in, 0) if first else _affine_ok(n_out, n_in, n_in))
+    x, aff = _unwrap(x, ok)
+    use_act = act if act is not None and not first and _act_ok(n_out, n_in, n_in) else None
+    y = _SageConv.apply(x, wl, bl, wr, graph, mean, aff, use_act)
+    if use_act is not None:
+        y._hgv_act = use_act
+    return y
 
 
-def dual_linear(xa, wa, xb=None, wb=None, bias=None):
-    return _DualLinear.apply(xa, wa, xb, wb, bias)
+def dual_linear(xa, wa, xb=None, wb=None, bias=None, act=None):
+    n, ka, kb = wa.size(0), wa.size(1), (wb.size(1) if (xb is not None and wb is not None) else 0)
+    ok = _affine_ok(n, ka, kb)
+    (xa, aff_a), (xb, aff_b) = _unwrap(xa, ok), (_unwrap(xb, ok) if xb is not None else (None, None))
+    use_act = act if act is not None and _act_ok(n, ka, kb) else None
+    y = _DualLinear.apply(xa, wa, xb, wb, bias, aff_a, aff_b, use_act)
+    if use_act is not None:
+        y._hgv_act = use_act
+    return y
 
 
 # --------------------------------------------------------------------------------------
@@ -1051,18 +1394,20 @@ class _BnActEval(torch.autograd.Function):
         return gy, dgamma, dbeta, None, None, None, None
 
 
-def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
+def bn_act(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False, noise=None):
     """relu? -> Dropout(p) -> BatchNorm1d, fused.  ``bn`` supplies affine parameters and running buffers.  With ``fork``
-    the result is returned as a pair of handles for its two consumers (see :class:`_BnAct`)."""
+    the result is returned as a pair of handles for its two consumers (see :class:`_BnAct`).  ``noise``: a dropout draw
+    ``(mask, seed, offset, counter)`` the caller has already taken for this call."""
+    y = plain(y)
     _lib.require_cuda(y)
     if fork and not (training and torch.is_grad_enabled() and y.requires_grad):
-        out = bn_act(y, bn, relu, p, training)
+        out = bn_act(y, bn, relu, p, training, noise=noise)
         return out, out
     if not training:
         return _BnActEval.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, bn.eps)
     mask, seed, offset, ctr = None, 0, 0, None
     if p > 0.0:
-        mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
+        mask, seed, offset, ctr = noise if noise is not None else current_noise().dropout(y.shape, y.device)
     momentum = bn.momentum if bn.momentum is not None else 0.1
     if on_branch_stream():
         # The trunk may be updating this module's running statistics at this moment (the other encode pass).  The
@@ -1160,6 +1505,7 @@ class _MSE(torch.autograd.Function):
 
 
 def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    recon, x = plain(recon), plain(x)
     _lib.require_cuda(recon, x)
     if recon.shape != x.shape:
         raise _lib.HgvError(f"mse_loss: shapes differ {tuple(recon.shape)} vs {tuple(x.shape)}")
@@ -1232,6 +1578,7 @@ class _GatAggregate(torch.autograd.Function):
 def gat_aggregate(xw, att, loop_graph: Graph, slope: float, p: float, training: bool, bias=None):
     """Attention-weighted neighbour sum of GATConv (+ bias) from the projected features ``xw`` [N, C] and the stacked
     attention vectors ``att`` [2, C] (att_src; att_dst)."""
+    xw = plain(xw)
     mask, seed, offset, ctr = None, 0, 0, None
     if training and p > 0.0:
         mask, seed, offset, ctr = current_noise().dropout((loop_graph.num_edges, 1), xw.device)
@@ -1368,6 +1715,7 @@ class _GcnAggregate(torch.autograd.Function):
 
 def gcn_aggregate(h: torch.Tensor, loop_graph: Graph) -> torch.Tensor:
     """D^-1/2 (A + I) D^-1/2 h over the loop-augmented graph (degrees over targets, self loops included)."""
+    h = plain(h)
     _lib.require_cuda(h)
     return _GcnAggregate.apply(h, loop_graph, loop_graph.gcn_dis)
 
@@ -1400,6 +1748,7 @@ class _GatherScale(torch.autograd.Function):
 
 
 def gather_rows(x, perm, scale=None):
+    x = plain(x)
     _lib.require_cuda(x, perm)
     return _GatherScale.apply(x, perm, scale)
 

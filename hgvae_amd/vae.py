@@ -77,7 +77,16 @@ class _VAEBase(nn.Module):
         return Fn.bn_act(y, bn, relu, p, self.training, fork=fork)
 
     def _sage_level(self, seq, x, g, fork: bool = False):
-        return self._finish(seq[0](x, g), seq[1], seq[2], relu=True, fork=fork)
+        conv, drop, bn = seq[0], seq[1], seq[2]
+        return Fn.bn_level(lambda act: conv(x, g, act=act), x.size(0), bn, True, drop.p, self.training, fork=fork)
+
+    def _linear_level(self, xa, xb, lin, dropout, bn, relu: bool):
+        """Decoder level: Linear over xa (or over [xa | xb]) -> (relu) -> dropout -> batch norm."""
+        if xb is None:
+            make = lambda act: Fn.dual_linear(xa, lin.weight, None, None, lin.bias, act=act)      # noqa: E731
+        else:
+            make = lambda act: Fn.concat_linear(xa, xb, lin.weight, lin.bias, act=act)            # noqa: E731
+        return Fn.bn_level(make, xa.size(0), bn, relu, dropout.p if dropout is not None else 0.0, self.training)
 
     def reparameterize(self, mean, log_std):
         ml = join_head(mean, log_std)
@@ -134,7 +143,7 @@ class SkipconVAE(_VAEBase):
         conv, drop, bn = self.encoder1[0], self.encoder1[1], self.encoder1[2]
         memo = self._conv1_memo
         if memo is None:
-            return self._finish(conv(x, g), drop, bn, relu=True, fork=True)
+            return self._sage_level(self.encoder1, x, g, fork=True)
         if memo and memo[0] is x and memo[1] is g and memo[2] == torch.is_grad_enabled():
             kind, kept = memo[3]
             memo.clear()
@@ -171,9 +180,9 @@ class SkipconVAE(_VAEBase):
 
     def decode(self, z, skip1, skip2):
         d1, d2, d3 = self.decoder1, self.decoder2, self.decoder3
-        h1 = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=False)
-        h2 = self._finish(Fn.concat_linear(h1, skip1, d2[0].weight, d2[0].bias), d2[1], d2[2], relu=False)
-        h3 = self._finish(Fn.concat_linear(h2, skip2, d3[0].weight, d3[0].bias), d3[1], d3[2], relu=False)
+        h1 = self._linear_level(z, None, d1[0], d1[1], d1[2], relu=False)
+        h2 = self._linear_level(h1, skip1, d2[0], d2[1], d2[2], relu=False)
+        h3 = self._linear_level(h2, skip2, d3[0], d3[1], d3[2], relu=False)
         return Fn.dual_linear(h3, d3[3].weight, None, None, d3[3].bias)
 
     def forward(self, x, edge_index, batch=None):
@@ -254,7 +263,7 @@ class PoolVAE(_VAEBase):
 
     def decode(self, z, x1):
         d1 = self.decoder1
-        h = self._finish(Fn.dual_linear(z, d1[0].weight, None, None, d1[0].bias), d1[1], d1[2], relu=True)
+        h = self._linear_level(z, None, d1[0], d1[1], d1[2], relu=True)
         # (h + x1) W^T as one K-concatenated product h W^T + x1 W^T: the sum is never written
         w = self.decoder2[0].weight
         return Fn.dual_linear(h, w, x1, w, self.decoder2[0].bias)
@@ -317,8 +326,7 @@ class CustomPoolVAE(PoolVAE):
         zt = self.x1_transform
         x1_t = Fn.dual_linear(x1, zt.weight, None, None, zt.bias)
         d1 = self.decoder1
-        y = Fn.concat_linear(z, x1_t, d1[0].weight, d1[0].bias)
-        h = self._finish(y, d1[1], d1[2], relu=True)
+        h = self._linear_level(z, x1_t, d1[0], d1[1], d1[2], relu=True)
         return Fn.dual_linear(h, self.decoder2[0].weight, None, None, self.decoder2[0].bias)
 
     def forward(self, x, edge_index, batch):
@@ -354,7 +362,7 @@ def train_vae_custom_pool(model, loader, optimizer, clip_value=None, device=None
 
 def custom_pool_step_loss(model, x, edge_index, batch):
     Fn.no_branches()
-    with Fn.weight_images(model):
+    with Fn.weight_images(model), Fn.deferred_levels():
         with Fn.bounded_pooling():      # the coarse graph is discarded here: no need to read its size back
             reconstruction, _, _, mean, log_std, x1 = model(x, edge_index, batch)
         recon_loss = model.recon_loss(reconstruction, x, mean, log_std, edge_index, x1)
@@ -430,7 +438,8 @@ def train_step_loss(model, x, edge_index, batch=None, lambda_kl=1.0):
     share = getattr(model, "share_first_conv", None)
     Fn.no_branches()
     # the loss looks at the reconstruction only: pooled graphs (pool variants) may stay at their capacity
-    with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling(), Fn.weight_images(model):
+    with share() if share is not None else contextlib.nullcontext(), Fn.bounded_pooling(), Fn.weight_images(model), \
+            Fn.deferred_levels():
         out = model(x, edge_index, batch)
         memo = getattr(model, "_conv1_memo", None)
         if memo and len(memo) > 4 and memo[4] is not None:

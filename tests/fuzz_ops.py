@@ -484,7 +484,10 @@ def fuzz_model(rng, gen):
 
 
 WIDEN_CAP = 50.0              # largest factor by which a whole-step bar may follow the fp32 CPU restatement / the conditioning
-WIDENED_SHARE = 0.10          # largest share of a seed's whole-step cases that may need a widened bar (at least one case)
+# Largest share of a seed's whole-step cases that may need a widened bar (at least one case).  A seed of ~330 cases holds
+# 22-28 whole-step cases; measured on the committed seeds 11 / 12 / 5 / 15: 1 of 24, 0 of 23, 2 of 28 (one of them at the
+# cap), 0 of 22 - 3 % over all four.
+WIDENED_SHARE = 0.08
 
 
 def run(cases: int, seed: int, verbose: bool = False):
