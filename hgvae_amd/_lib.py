@@ -76,17 +76,16 @@ SIGNATURES = {
     "hgv_pack16h_bytes": (_sz, [_i32, _i32, _i32]),
     "hgv_pack16h_weights_multi": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgv_gemm_nt16h": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
-    "hgv_gemm_nt16h_act_supported": (C.c_int, [_i32, _i32, _i32]),
-    "hgv_gemm_nt16h_act": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _i32, _f32, _vp, _u64, _u64,
-                                     _vp, _vp]),
-    "hgv_pack16h_weights_affine": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp,
-                                             _vp]),
+    "hgv_pack16h_weights_affine": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _vp, _vp, _i32, _vp, _vp,
+                                             _vp, _vp]),
+    "hgv_agg_fwd_ind": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "hgv_agg_fwd_affine": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _vp]),
-    "hgv_bn_stats": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "hgv_bn_stats_act": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _vp, _f32, _vp, _vp, _f32, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hgv_bn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "hgv_bn_act_bwd_pre": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                      _i32, _vp, _sz, _vp]),
-    "hgv_wgrad_finish": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "hgv_wgrad_finish": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "hgv_row_range_flag": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp]),
     "hgv_gemm_nt16h_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hgv_gemm_nt16_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),

@@ -69,7 +69,14 @@ struct AggArgs {
     // column, the mean over the neighbours' x rows is (mean over their a rows) * col_s + col_t for a row with neighbours and
     // 0 for a row without (row_mode 1 only); col_s / col_t hold nchunks * VEC floats
     const float* col_s; const float* col_t;
+    // optional indicator column: column ind_col (one of the pad columns [F, nchunks * VEC)) of the output row receives
+    // 1.0f when the row has neighbours and 0.0f when it has none; -1: pad columns are whatever the sums give
+    int ind_col;
 };
+
+__device__ __forceinline__ void vset(float& a, int j, float v) { a = v; }
+__device__ __forceinline__ void vset(float2& a, int j, float v) { if (j == 0) a.x = v; else a.y = v; }
+__device__ __forceinline__ void vset(float4& a, int j, float v) { if (j == 0) a.x = v; else if (j == 1) a.y = v; else if (j == 2) a.z = v; else a.w = v; }
 
 __device__ __forceinline__ void vaffine(float& a, const float* s, const float* t, bool any) { a = __fmaf_rn(a, s[0], any ? t[0] : 0.f); }
 __device__ __forceinline__ void vaffine(float2& a, const float* s, const float* t, bool any) {
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(128) void k_aggregate(const AggArgs a) {
             if (a.row_mode == 1) vdiv(acc[q], (float)(d > 1 ? d : 1));
             else if (a.row_mode == 2) vscale(acc[q], a.row_scale[row]);
             if (a.col_s) vaffine(acc[q], a.col_s + coff[q], a.col_t + coff[q], d > 0);
+            if (a.ind_col >= coff[q] && a.ind_col < coff[q] + VEC) vset(acc[q], a.ind_col - coff[q], d > 0 ? 1.f : 0.f);
             if (owns[q]) {
                 if (a.add) vadd(acc[q], *reinterpret_cast<const V*>(a.add + row * a.ldadd + coff[q]));
                 *reinterpret_cast<V*>(a.out + row * a.ldo + coff[q]) = acc[q];
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(64 * LONG_WAVES) void k_aggregate_long(const AggArg
                 if (a.row_mode == 1) vdiv(tot, (float)(len > 1 ? len : 1));
                 else if (a.row_mode == 2) vscale(tot, a.row_scale[row]);
                 if (a.col_s) vaffine(tot, a.col_s + coff, a.col_t + coff, len > 0);
+                if (a.ind_col >= coff && a.ind_col < coff + VEC) vset(tot, a.ind_col - coff, len > 0 ? 1.f : 0.f);
                 if (owns) {
                     if (a.add) vadd(tot, *reinterpret_cast<const V*>(a.add + row * a.ldadd + coff));
                     *reinterpret_cast<V*>(a.out + row * a.ldo + coff) = tot;
@@ -329,7 +338,7 @@ extern "C" int hgv_agg_fwd(const int32_t* rowptr, const int32_t* col, int64_t n_
     HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd: null buffer");
     HGV_REQUIRE(ldx >= F && ldo >= F && (!add || ldadd >= F), HGV_EINVAL, "agg_fwd: leading dimension < F");
     HGV_REQUIRE(row_mode >= 0 && row_mode <= 2 && (row_mode != 2 || row_scale), HGV_EINVAL, "agg_fwd: bad row_mode");
-    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, 0, nullptr, nullptr};
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, 0, nullptr, nullptr, -1};
     return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream);
 }
 
@@ -353,7 +362,7 @@ static int agg_fwd_long_any(const int32_t* rowptr, const int32_t* col, int64_t n
                                 int F, int row_mode, const float* row_scale, const float* edge_w, const float* nbr_w,
                                 const float* add, int64_t ldadd, float* out, int64_t ldo, int threshold,
                                 const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
-                                const float* col_s, const float* col_t, hipStream_t stream) {
+                                const float* col_s, const float* col_t, hipStream_t stream, int ind_col = -1) {
     HGV_REQUIRE(n_rows >= 0 && F >= 0, HGV_EINVAL, "agg_fwd_long: negative size");
     if (n_rows == 0 || F == 0) return HGV_OK;
     HGV_REQUIRE(rowptr && x && out, HGV_EINVAL, "agg_fwd_long: null buffer");
@@ -362,7 +371,9 @@ static int agg_fwd_long_any(const int32_t* rowptr, const int32_t* col, int64_t n
     HGV_REQUIRE(threshold > 0 && long_rows && long_count && long_cap > 0, HGV_EINVAL, "agg_fwd_long: bad long-row list");
     HGV_REQUIRE((col_s == nullptr) == (col_t == nullptr) && (!col_s || (row_mode == 1 && !add && hgv_aligned(col_s, 16) && hgv_aligned(col_t, 16))),
                 HGV_EINVAL, "agg_fwd_affine: column scale and shift come together, 16-byte aligned, with the row mean and no addend");
-    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold, col_s, col_t};
+    HGV_REQUIRE(ind_col < 0 || (ind_col >= F && ind_col < (F + 3) / 4 * 4 && ldo > ind_col && hgv_aligned(x, 16) && hgv_aligned(out, 16) &&
+                                ldx % 4 == 0 && ldo % 4 == 0), HGV_EINVAL, "agg_fwd_ind: the indicator column must be a pad column of 16-byte rows");
+    AggArgs a{rowptr, col, x, ldx, n_rows, 0, 0, row_mode, row_scale, edge_w, nbr_w, add, ldadd, out, ldo, threshold, col_s, col_t, ind_col};
     return launch_aggregate(a, F, edge_w != nullptr || nbr_w != nullptr, stream, run_long_pass ? long_rows : nullptr, long_count,
                             long_cap);
 }
@@ -397,4 +408,17 @@ extern "C" int hgv_agg_bwd(const int32_t* rowptr_t, const int32_t* col_t, int64_
                            int64_t ldadd, float* gx, int64_t ldgx, hipStream_t stream) {
     return hgv_agg_fwd(rowptr_t, col_t, n_rows, g, ldg, F, 0, nullptr, edge_w_t, inv_deg, add, ldadd, gx, ldgx,
                        stream);
+}
+
+// Mean aggregation (hgv_agg_fwd_long with row_mode 1, no weights, no addend) that also writes an indicator into the pad
+// column ind_col (F <= ind_col < 4 * ceil(F / 4)) of every output row: 1.0f for a row with neighbours, 0.0f for one
+// without.  For source rows that stand for x = d * s + t: mean_j x_j = mean_j(d_j) * s + t * indicator, so a projection
+// that follows can take [mean(d) | indicator] as its operand with weights [W diag(s) | W t] (hgv_pack16h_weights_affine)
+// and the aggregation itself costs what it costs on an ordinary matrix.
+extern "C" int hgv_agg_fwd_ind(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* d, int64_t ldd, int F,
+                               float* out, int64_t ldo, int ind_col, int threshold, const int32_t* long_rows,
+                               const int32_t* long_count, int long_cap, int run_long_pass, hipStream_t stream) {
+    HGV_REQUIRE(ind_col >= 0, HGV_EINVAL, "agg_fwd_ind: no indicator column");
+    return agg_fwd_long_any(rowptr, col, n_rows, d, ldd, F, 1, nullptr, nullptr, nullptr, nullptr, 0, out, ldo, threshold,
+                            long_rows, long_count, long_cap, run_long_pass, nullptr, nullptr, stream, ind_col);
 }

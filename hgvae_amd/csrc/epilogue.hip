@@ -133,8 +133,15 @@ constexpr int EP_PIVOT_ROWS = 8;
 
 // partial layout: [set][block][2][Hp] = (mean_b, M2_b), Hp = CH*4.  NS = 2: two noise sets (Philox offsets a.offset and
 // a.offset2) over one read of y - the statistics of two dropout draws of the same pre-activation.
-template <bool VEC, int NS>
-__global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial) {
+// WD: the activated values d are also written back over y (one set only): a dropped element as -0.0f when there is no relu
+// in front (a kept zero as +0.0f), so that later passes read relu and dropout off the stored values (EpArgs::pre).
+__device__ __forceinline__ float stored_d(const EpArgs& a, float d, float k) {
+    if (a.mode != 0 && k == 0.f) return a.relu ? 0.f : -0.f;
+    return d == 0.f ? 0.f : d;
+}
+
+template <bool VEC, int NS, bool WD = false>
+__global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial, float* __restrict__ d_out = nullptr) {
     __shared__ float4 sh[512];
     __shared__ float4 sh2[512];
     const int t = threadIdx.x;
@@ -182,8 +189,18 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
 #pragma unroll
             for (int set = 0; set < NS; ++set) {
-                float4 d[2];
-                apply_d2(a, row, cp, yv, d, nullptr, set);
+                float4 d[2], kk[2];
+                apply_d2(a, row, cp, yv, d, WD ? kk : nullptr, set);
+                if (WD) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (h < nh) {
+                            const float4 w = make_float4(stored_d(a, d[h].x, kk[h].x), stored_d(a, d[h].y, kk[h].y),
+                                                         stored_d(a, d[h].z, kk[h].z), stored_d(a, d[h].w, kk[h].w));
+                            st4<VEC>(d_out, a.ldy, row, cc[h], a.H, w);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float tx = d[h].x - s[set][h].x, ty = d[h].y - s[set][h].y, tz = d[h].z - s[set][h].z, tw = d[h].w - s[set][h].w;
@@ -808,33 +825,35 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int6
     return HGV_OK;
 }
 
-// ---- levels whose activation was applied by the producing kernel -------------------------------------------------------
-// The projection that feeds a level can apply relu -> dropout itself while it stores its tile (hgv_gemm_nt16h_act), so the
-// matrix between the two holds d = dropout(relu(y)) instead of y.  Then the level needs only the column statistics of d:
-// the normalisation out = d * col_s + col_t (col_s = gamma * rstd, col_t = beta - mean * col_s) is handed to the
-// consumers as two vectors - a following projection folds them into its weights (hgv_pack16h_weights_affine), a mean
-// aggregation applies them to its finished rows (hgv_agg_fwd_affine) - and `out` is never written
+// ---- levels whose normalisation is left to their consumers ----------------------------------------------------------------
+// The pass that takes a level's column statistics can leave d = dropout(relu(y)) behind in place of y.  Then the
+// normalisation out = d * col_s + col_t (col_s = gamma * rstd, col_t = beta - mean * col_s) is handed to the consumers as
+// two vectors - a following projection folds them into its weights (hgv_pack16h_weights_affine), a mean aggregation
+// applies them to its finished rows (hgv_agg_fwd_affine) - and `out` is never written
 // (gvae/gvae_skipcon.py:105-107 -> :110, :124-130: Dropout / BatchNorm1d outputs consumed by the next SAGEConv / Linear).
-// hgv_bn_stats: statistics (save_mean / save_rstd), running-buffer update and col_s / col_t (4 * ceil(H / 4) floats each,
-// pad columns zero) of the activated matrix d [N, H].
-extern "C" int hgv_bn_stats(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
-                            float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
-                            float* save_mean, float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes,
-                            hipStream_t stream) {
+// hgv_bn_stats_act: y [N, H] is overwritten with d = dropout(relu(y)) (relu / p / mask / Philox arguments as for
+// hgv_bn_act_fwd; without a relu a dropped element is stored as -0.0f and a kept zero as +0.0f) in the same pass that takes
+// the column statistics of d: save_mean / save_rstd, the running-buffer update and col_s / col_t (4 * ceil(H / 4) floats
+// each, pad columns zero).  One read and one write of the matrix instead of the two reads and one write of
+// hgv_bn_act_fwd, and nothing of the level is written again.
+extern "C" int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask, uint64_t seed,
+                                uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
+                                float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                                float* save_mean, float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
     EpArgs a; int nb;
-    int rc = make_args(a, d, ldd, N, H, 0, 0.f, nullptr, 0, 0, nullptr, &nb);
+    int rc = make_args(a, y, ldy, N, H, relu, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
-    HGV_REQUIRE(save_mean && save_rstd && col_s && col_t && ws, HGV_EINVAL, "bn_stats: null buffer");
-    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_stats: workspace too small or misaligned");
-    a.pre = 1;
+    HGV_REQUIRE(save_mean && save_rstd && col_s && col_t && ws, HGV_EINVAL, "bn_stats_act: null buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_stats_act: workspace too small or misaligned");
     const int Hp = a.CH * 4;
     float* partial = (float*)ws;
-    if (vec4_ok(d, ldd, Hp)) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
-    else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    if (vec4_ok(y, ldy, Hp)) hipLaunchKernelGGL((k_ep_stats<true, 1, true>), dim3(nb), dim3(256), 0, stream, a, partial, y);
+    else hipLaunchKernelGGL((k_ep_stats<false, 1, true>), dim3(nb), dim3(256), 0, stream, a, partial, y);
     hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
                        a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 1,
                        gamma, beta, col_s, col_t);
-    HGV_CHECK_LAUNCH("bn_stats");
+    HGV_CHECK_LAUNCH("bn_stats_act");
     return HGV_OK;
 }
 
@@ -855,8 +874,8 @@ extern "C" int hgv_bn_apply(const float* d, int64_t ldd, int64_t N, int H, const
     return HGV_OK;
 }
 
-// Backward of such a level: hgv_bn_act_bwd with the activated matrix d in place of y.  dy is the gradient with respect to
-// the projection's output BEFORE its activation (the producing operator is linear from there on); p as in the forward.
+// Backward of such a level: hgv_bn_act_bwd with the activated matrix d in place of y (relu and dropout are read off the
+// stored values); dy is the gradient with respect to y; p as in the forward.
 extern "C" int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* d, int64_t ldd,
                                   int64_t N, int H, int relu, float p, const float* gamma, const float* save_mean,
                                   const float* save_rstd, float* dy, int64_t lddy, float* dgamma, float* dbeta, int accumulate,
@@ -883,10 +902,11 @@ extern "C" int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, 
 
 // Weight-gradient finish for operands that were handed over un-normalised.  With x = a * s + t column by column,
 //   G^T x = (G^T a) diag(s) + colsum(G) t^T:
-// dst[n,k] (+)= raw[n,k] * s[k] + colsum[n] * t[k]   (s / t null: dst (+)= raw).  Up to three jobs per launch (the two
-// halves of a K-concatenated weight and the bias vector as an N x 1 matrix).
+// dst[n,k] (+)= raw[n,k] * s[k] + colsum[n * cs_stride] * t[k]   (s / t null: dst (+)= raw).  Up to three jobs per launch
+// (the two halves of a K-concatenated weight and the bias vector as an N x 1 matrix).  colsum with a stride: for an
+// operand [mean(d) | indicator] the sum that multiplies t is the raw product's indicator column.
 namespace {
-struct FinishJob { float* dst; int64_t lddst; const float* raw; int64_t ldraw; int N, K; const float* s; const float* t; const float* colsum; };
+struct FinishJob { float* dst; int64_t lddst; const float* raw; int64_t ldraw; int N, K; const float* s; const float* t; const float* colsum; int64_t cs_stride; };
 struct FinishArgs { FinishJob job[3]; int njobs; int accumulate; };
 __global__ __launch_bounds__(256) void k_wgrad_finish(const FinishArgs f) {
     const FinishJob& j = f.job[blockIdx.y];
@@ -894,7 +914,7 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const FinishArgs f) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int n = (int)(e / j.K), k = (int)(e - (int64_t)n * j.K);
         float v = j.raw[(int64_t)n * j.ldraw + k];
-        if (j.s) v = __fmaf_rn(v, j.s[k], j.colsum[n] * j.t[k]);
+        if (j.s) v = __fmaf_rn(v, j.s[k], j.colsum[(int64_t)n * j.cs_stride] * j.t[k]);
         float* d = j.dst + (int64_t)n * j.lddst + k;
         *d = f.accumulate ? *d + v : v;
     }
@@ -903,8 +923,8 @@ __global__ __launch_bounds__(256) void k_wgrad_finish(const FinishArgs f) {
 
 extern "C" int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* lddst, const float* const* raw, const int64_t* ldraw,
                                 const int* N, const int* K, const float* const* s, const float* const* t,
-                                const float* const* colsum, int accumulate, hipStream_t stream) {
-    HGV_REQUIRE(njobs >= 1 && njobs <= 3 && dst && lddst && raw && ldraw && N && K && s && t && colsum, HGV_EINVAL,
+                                const float* const* colsum, const int64_t* cs_stride, int accumulate, hipStream_t stream) {
+    HGV_REQUIRE(njobs >= 1 && njobs <= 3 && dst && lddst && raw && ldraw && N && K && s && t && colsum && cs_stride, HGV_EINVAL,
                 "wgrad_finish: 1..3 jobs and non-null arrays expected");
     FinishArgs f{};
     f.njobs = njobs; f.accumulate = accumulate;
@@ -912,7 +932,7 @@ extern "C" int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* ldd
     for (int q = 0; q < njobs; ++q) {
         HGV_REQUIRE(dst[q] && raw[q] && N[q] > 0 && K[q] > 0 && lddst[q] >= K[q] && ldraw[q] >= K[q], HGV_EINVAL, "wgrad_finish: bad job %d", q);
         HGV_REQUIRE((s[q] == nullptr) == (t[q] == nullptr) && (!s[q] || colsum[q]), HGV_EINVAL, "wgrad_finish: job %d needs s, t and colsum together", q);
-        f.job[q] = FinishJob{dst[q], lddst[q], raw[q], ldraw[q], N[q], K[q], s[q], t[q], colsum[q]};
+        f.job[q] = FinishJob{dst[q], lddst[q], raw[q], ldraw[q], N[q], K[q], s[q], t[q], colsum[q], cs_stride[q]};
         most = (int64_t)N[q] * K[q] > most ? (int64_t)N[q] * K[q] : most;
     }
     int64_t blocks = hgv_cdiv(most, 256);

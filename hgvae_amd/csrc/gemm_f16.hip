@@ -83,6 +83,9 @@ struct PackHArgs {
     // holds W_s diag(cs_s) and bias_out[n] = bias_in[n] + sum_k W1[n,k] ct1[k] + sum_k W2[n,k] ct2[k]
     const float* cs1; const float* ct1; const float* cs2; const float* ct2;
     const float* bias_in; float* bias_out;
+    // ind1: source 1 has K1 - 1 weight columns and the image's column K1 - 1 holds sum_k W1[n,k] ct1[k] instead of that
+    // sum going into the bias: the operand's last column is an indicator that switches the shift on per row
+    int ind1;
 };
 
 constexpr int PACKH_MAX_JOBS = 24;
@@ -108,25 +111,30 @@ __global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
     const int n = R;
     const int rows = g.rows;
     float amax = 0.f;
-    double shift = 0.0;                                           // sum_k W[n,k] ct[k], in float64
+    double shift1 = 0.0, shift2 = 0.0;                            // sum_k W_s[n,k] ct_s[k], in float64
+    const int kw1 = g.K1 - (a.ind1 ? 1 : 0);                      // weight columns of source 1
     if (n < g.N) {
-        for (int k = lane; k < g.K1; k += 64) {
+        for (int k = lane; k < kw1; k += 64) {
             const float w = a.W1[(int64_t)n * a.sn1 + (int64_t)k * a.sk1];
             amax = fmaxf(amax, __builtin_fabsf(a.cs1 ? w * a.cs1[k] : w));
-            if (a.ct1) shift += (double)w * (double)a.ct1[k];
+            if (a.ct1) shift1 += (double)w * (double)a.ct1[k];
         }
         for (int k = lane; k < g.K2; k += 64) {
             const float w = a.W2[(int64_t)n * a.sn2 + (int64_t)k * a.sk2];
             amax = fmaxf(amax, __builtin_fabsf(a.cs2 ? w * a.cs2[k] : w));
-            if (a.ct2) shift += (double)w * (double)a.ct2[k];
+            if (a.ct2) shift2 += (double)w * (double)a.ct2[k];
         }
     }
+    float extra = 0.f;                                            // the indicator's weight
+    if (a.bias_out != nullptr) {
+        shift1 = hgv_wave_sum_d(shift1);
+        shift2 = hgv_wave_sum_d(shift2);
+        if (a.ind1) extra = (float)shift1;
+        if (lane == 0 && n < g.N) a.bias_out[n] = (float)((a.bias_in ? (double)a.bias_in[n] : 0.0) + shift2 + (a.ind1 ? 0.0 : shift1));
+    }
+    amax = fmaxf(amax, __builtin_fabsf(extra));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
-    if (a.bias_out != nullptr) {
-        shift = hgv_wave_sum_d(shift);
-        if (lane == 0 && n < g.N) a.bias_out[n] = (float)((a.bias_in ? (double)a.bias_in[n] : 0.0) + shift);
-    }
     float inv;
     const float s = scale_for(amax, inv);
     const size_t piece_elems = (size_t)rows * 32;
@@ -138,7 +146,8 @@ __global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
         if (n < g.N) {
             if (blk < g.nb1) {
                 const int k = 8 * blk + j;
-                if (k < g.K1) { x = a.W1[(int64_t)n * a.sn1 + (int64_t)k * a.sk1]; if (a.cs1) x *= a.cs1[k]; }
+                if (k < kw1) { x = a.W1[(int64_t)n * a.sn1 + (int64_t)k * a.sk1]; if (a.cs1) x *= a.cs1[k]; }
+                else if (k < g.K1) x = extra;
             } else if (blk < g.nb1 + g.nb2) {
                 const int k = 8 * (blk - g.nb1) + j;
                 if (k < g.K2) { x = a.W2[(int64_t)n * a.sn2 + (int64_t)k * a.sk2]; if (a.cs2) x *= a.cs2[k]; }
@@ -158,48 +167,6 @@ __global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
     }
 }
 
-// Optional activation applied to the output tile before it is stored: C <- dropout(relu(C)) (relu optional), the head of
-// a level's relu -> Dropout -> BatchNorm1d tail (gvae/gvae_skipcon.py:105-107).  Keep decisions: explicit mask [M, N]
-// (uint8) or Philox4x32-7 keyed by (seed, offset, row, n-tile pair, lane quarter), 16 random bits per element.  Nothing
-// regenerates these decisions later: a dropped element is stored as -0.0f when there is no relu in front (a kept zero as
-// +0.0f), so the backward pass reads the mask off the stored values; behind a relu every zero has a zero derivative anyway.
-struct ActH {
-    int on; int relu; int mode;          // mode 0: no dropout, 1: explicit mask, 2: Philox
-    float scale; uint32_t thresh;        // kept values are multiplied by scale = 1 / (1 - p); keep iff 16 bits >= thresh
-    const uint8_t* mask; int H;
-    uint64_t seed, offset; const uint64_t* offset_dev;
-};
-
-// o = the 4 consecutive outputs of row `row` starting at column 16 gn + 4 kq; rnd carries the Philox words of the
-// n-tile pair (gn >> 1) from its even to its odd tile
-__device__ __forceinline__ void act_tile(const ActH& act, int64_t row, int gn, int kq, bool first, uint4& rnd, f32x4& o) {
-    bool keep[4] = {true, true, true, true};
-    if (act.mode == 1) {
-        const int c0 = 16 * gn + 4 * kq;
-        const uint8_t* m = act.mask + row * act.H + c0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) keep[r] = c0 + r < act.H && m[r] != 0;
-    } else if (act.mode == 2) {
-        if (first || (gn & 1) == 0) {
-            const HgvPhilox ph(act.seed);
-            const uint64_t off = act.offset + (act.offset_dev ? act.offset_dev[0] : 0ull);
-            rnd = ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)((gn >> 1) * 4 + kq) << 8) ^ 0x80000000u,
-                               (uint32_t)off, (uint32_t)(off >> 32));
-        }
-        const uint32_t w0 = (gn & 1) ? rnd.z : rnd.x, w1 = (gn & 1) ? rnd.w : rnd.y;
-        keep[0] = (w0 & 0xffffu) >= act.thresh; keep[1] = (w0 >> 16) >= act.thresh;
-        keep[2] = (w1 & 0xffffu) >= act.thresh; keep[3] = (w1 >> 16) >= act.thresh;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float v = o[r];
-        if (act.relu) v = fmaxf(v, 0.f);
-        v *= act.scale;
-        if (v == 0.f) v = 0.f;                                   // a kept zero is +0
-        o[r] = keep[r] ? v : (act.relu ? 0.f : -0.f);
-    }
-}
-
 struct NtHArgs {
     const float* A1; int64_t lda1; const float* A2; int64_t lda2;
     GeoH g;
@@ -209,7 +176,6 @@ struct NtHArgs {
     int wgs0;
     int paced;
     const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
-    ActH act;
 };
 
 // every thread of the launch reads the same word, written by an earlier kernel of the stream: a uniform early exit
@@ -258,7 +224,7 @@ __device__ __forceinline__ SplitH split8h(const f32x4 (&av)[2], float s) {
     return o;
 }
 
-template <int NT, int RING, bool ACT = false>
+template <int NT, int RING>
 __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
     const GeoH& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
@@ -441,11 +407,6 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                     // weights as the row operand: lane (i, kq) register r = C[row i][16 n + 4 kq + r]
                     const int64_t row = ctile * 16 + i;
                     if (row < a.M) {
-                        uint4 rnd = make_uint4(0, 0, 0, 0);
-                        // the activation's parameters are fetched here, per tile, from the kernel arguments: hoisted out of
-                        // the main loop they would live in scalar registers across it (and spill)
-                        const ActH* actp = &a.act;
-                        if (ACT) asm volatile("" : "+s"(actp));
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             const int col = (t0 + n) * 16 + 4 * kq;
@@ -455,7 +416,6 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                                 f32x4 o;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) o[r] = (acc[n][r] * inv_cur) * iw[r] + bs[r];
-                                if (ACT) act_tile(*actp, row, t0 + n, kq, n == 0, rnd, o);
                                 *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
                             }
                         }
@@ -480,11 +440,11 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     if (a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NT, bool ACT = false>
+template <int NT>
 __global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
-    nth_body<NT, nth_ring<NT>(), ACT>(a, lds_raw, part, blockIdx.x, gridDim.x);
+    nth_body<NT, nth_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
 }
 
 template <int NT0, int NT1>
@@ -499,7 +459,7 @@ __global__ __launch_bounds__(64 * nth_waves<NT0>()) void k_gemm_nt16h_pair(const
 // Weights whose image does not fit in LDS (hidden width 256): 12 waves own one row tile each and all NT n tiles of
 // it; the 32-wide k chunks of the image are copied by all threads into one of two LDS buffers while the waves
 // multiply from the other (one barrier per chunk).  The scale of a row is fixed per row block the same way as above.
-template <int NT, bool ACT = false>
+template <int NT>
 __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
@@ -611,7 +571,6 @@ __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
         const int64_t tile = rb * 12 + wib;
         const int64_t row = tile * 16 + i;
         if (tile < a.ntiles && row < a.M) {
-            uint4 rnd = make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const int col = n * 16 + 4 * kq;
@@ -621,7 +580,6 @@ __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
                     f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (acc[n][r] * inv_cur) * iw[r] + bs[r];
-                    if (ACT) act_tile(a.act, row, n, kq, n == 0, rnd, o);
                     *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
                 }
             }
@@ -656,9 +614,9 @@ int raise_lds_h(Kern kern) {
 
 constexpr int nth_min_waves() { return 4; }
 
-template <int NT, bool ACT = false>
+template <int NT>
 int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
-    auto kern = k_gemm_nt16h<NT, ACT>;
+    auto kern = k_gemm_nt16h<NT>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
     const int cus = cu_count_h();
@@ -672,19 +630,6 @@ int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
 }
 
 int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t st) {
-    if (a.act.on) {
-        switch (nt) {
-            case 1: return launch_nth<1, true>(a, part, lds, st);
-            case 2: return launch_nth<2, true>(a, part, lds, st);
-            case 3: return launch_nth<3, true>(a, part, lds, st);
-            case 4: return launch_nth<4, true>(a, part, lds, st);
-            case 5: return launch_nth<5, true>(a, part, lds, st);
-            case 6: return launch_nth<6, true>(a, part, lds, st);
-            case 7: return launch_nth<7, true>(a, part, lds, st);
-            case 8: return launch_nth<8, true>(a, part, lds, st);
-            default: return launch_nth<9, true>(a, part, lds, st);
-        }
-    }
     switch (nt) {
         case 1: return launch_nth<1>(a, part, lds, st);
         case 2: return launch_nth<2>(a, part, lds, st);
@@ -698,9 +643,9 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
     }
 }
 
-template <int NT, bool ACT = false>
+template <int NT>
 int launch_nths_nt(const NtHArgs& a, hipStream_t st) {
-    auto kern = k_gemm_nt16hs<NT, ACT>;
+    auto kern = k_gemm_nt16hs<NT>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
     const size_t lds = (size_t)2 * 2 * NT * 1024 + side_bytes_h(a.g.chunks, NT);
@@ -711,18 +656,6 @@ int launch_nths_nt(const NtHArgs& a, hipStream_t st) {
 }
 
 int launch_nths(const NtHArgs& a, hipStream_t st) {
-    if (a.act.on) {
-        switch (a.g.tpp) {
-            case 2: return launch_nths_nt<2, true>(a, st);
-            case 4: return launch_nths_nt<4, true>(a, st);
-            case 6: return launch_nths_nt<6, true>(a, st);
-            case 9: return launch_nths_nt<9, true>(a, st);
-            case 12: return launch_nths_nt<12, true>(a, st);
-            case 16: return launch_nths_nt<16, true>(a, st);
-            case 18: return launch_nths_nt<18, true>(a, st);
-            default: return HGV_EUNSUPPORTED;
-        }
-    }
     switch (a.g.tpp) {
         case 2: return launch_nths_nt<2>(a, st);
         case 4: return launch_nths_nt<4>(a, st);
@@ -810,7 +743,7 @@ extern "C" int hgv_pack16h_weights_multi(int njobs, const float* const* W1, cons
         HGV_REQUIRE(geo_h(N[q], K1[q], K2[q], &a.g), HGV_EUNSUPPORTED, "pack16h_weights: %d x (%d + %d) does not fit in LDS", N[q], K1[q], K2[q]);
         HGV_REQUIRE(hgv_aligned(out[q], 16), HGV_EINVAL, "pack16h_weights: output must be 16-byte aligned");
         a.W1 = W1[q]; a.sn1 = sn1[q]; a.sk1 = sk1[q]; a.W2 = W2[q]; a.sn2 = sn2[q]; a.sk2 = sk2[q]; a.out = (_Float16*)out[q];
-        a.cs1 = a.ct1 = a.cs2 = a.ct2 = a.bias_in = nullptr; a.bias_out = nullptr;
+        a.cs1 = a.ct1 = a.cs2 = a.ct2 = a.bias_in = nullptr; a.bias_out = nullptr; a.ind1 = 0;
         jobs.first_block[q] = blocks;
         blocks += (a.g.parts * a.g.tpp * 16 + 3) / 4;
     }
@@ -825,10 +758,15 @@ extern "C" int hgv_pack16h_weights_multi(int njobs, const float* const* W1, cons
 // For operands that are handed over un-normalised: with x_s = a_s * cs_s + ct_s column by column (a batch-norm output
 // kept as its input a and the per-column scale / shift),  x_1 W1^T + x_2 W2^T + bias = a_1 (W1 diag(cs1))^T + a_2 (W2
 // diag(cs2))^T + bias_out.  W2 nullable (then K2 = 0).  cs / ct hold K1 / K2 floats.
+// indicator1 != 0: operand 1 carries one more column than W1 has (K1 = columns of W1 + 1), an indicator in {0, 1} per
+// row (hgv_agg_fwd_ind writes it: rows without neighbours aggregate to 0, not to the shift); the image's column K1 - 1
+// is sum_k W1[n,k] ct1[k], which then stays out of bias_out.
 extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* cs1, const float* ct1,
-                                          const float* W2, int64_t sn2, int64_t sk2, int K2, const float* cs2, const float* ct2,
-                                          int N, const float* bias_in, float* bias_out, void* out, hipStream_t stream) {
+                                          int indicator1, const float* W2, int64_t sn2, int64_t sk2, int K2, const float* cs2,
+                                          const float* ct2, int N, const float* bias_in, float* bias_out, void* out,
+                                          hipStream_t stream) {
     HGV_REQUIRE(W1 && out && bias_out && N > 0 && K1 > 0 && (W2 ? K2 > 0 : K2 == 0), HGV_EINVAL, "pack16h_weights_affine: bad arguments");
+    HGV_REQUIRE(!indicator1 || (K1 > 1 && ct1), HGV_EINVAL, "pack16h_weights_affine: an indicator column needs a shift vector and K1 > 1");
     PackHJobs jobs{};
     jobs.njobs = 1;
     PackHArgs& a = jobs.job[0];
@@ -836,6 +774,7 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
     HGV_REQUIRE(hgv_aligned(out, 16), HGV_EINVAL, "pack16h_weights_affine: output must be 16-byte aligned");
     a.W1 = W1; a.sn1 = sn1; a.sk1 = sk1; a.W2 = W2; a.sn2 = sn2; a.sk2 = sk2; a.out = (_Float16*)out;
     a.cs1 = cs1; a.ct1 = ct1; a.cs2 = W2 ? cs2 : nullptr; a.ct2 = W2 ? ct2 : nullptr; a.bias_in = bias_in; a.bias_out = bias_out;
+    a.ind1 = indicator1 ? 1 : 0;
     jobs.first_block[0] = 0;
     const int blocks = (a.g.parts * a.g.tpp * 16 + 3) / 4;
     for (int q = 1; q <= PACKH_MAX_JOBS; ++q) jobs.first_block[q] = blocks;
@@ -847,7 +786,7 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
-                          hipStream_t stream, const ActH* act = nullptr) {
+                          hipStream_t stream) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -860,7 +799,6 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const _Float16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
     a.gate = gate; a.gate_run_if = gate_run_if;
-    if (act) a.act = *act;
     int rc;
     if (a.g.stream) {
         rc = launch_nths(a, stream);
@@ -871,7 +809,6 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
         } else {
             const int nt1 = a.g.tiles - a.g.tpp;
             HGV_REQUIRE(nt1 >= 1 && (nt1 == a.g.tpp || nt1 == a.g.tpp - 1), HGV_EUNSUPPORTED, "gemm_nt16h: unexpected split %d + %d", a.g.tpp, nt1);
-            HGV_REQUIRE(!a.act.on, HGV_EUNSUPPORTED, "gemm_nt16h_act: images of two parts take no fused activation");
             rc = launch_nth_both(a, a.g.tpp, nt1, lds, stream);
         }
     }
@@ -892,30 +829,6 @@ extern "C" int hgv_gemm_nt16h_gated(const float* A1, int64_t lda1, int K1, const
                                     hipStream_t stream) {
     HGV_REQUIRE(gate != nullptr, HGV_EINVAL, "gemm_nt16h_gated: null gate");
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, gate, run_if_set ? 1 : 0, stream);
-}
-
-// 1 when hgv_gemm_nt16h_act can run this shape (an image of one part, resident or streamed)
-extern "C" int hgv_gemm_nt16h_act_supported(int N, int K1, int K2) {
-    GeoH g;
-    return (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && (g.stream || g.parts == 1)) ? 1 : 0;
-}
-
-// hgv_gemm_nt16h followed by the head of the level's tail in the same launch: C <- dropout(relu(C)) (relu != 0: with the
-// relu; p: dropout probability in [0, 1); mask: explicit keep mask [M, N] uint8, contiguous, or null for Philox keep
-// decisions keyed by (seed, offset + *offset_dev, row, column group)).  Kept values are multiplied by 1 / (1 - p); without a
-// relu a dropped element is stored as -0.0f and a kept zero as +0.0f (the mask can be read off the result).  Pad columns
-// [N, ldc) come out as zeros (of either sign).
-extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
-                                  const float* bias, int64_t M, int N, float* C, int64_t ldc, int relu, float p,
-                                  const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                                  hipStream_t stream) {
-    HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "gemm_nt16h_act: dropout p=%f outside [0,1)", p);
-    ActH act{};
-    act.on = 1; act.relu = relu ? 1 : 0; act.mode = p > 0.f ? (mask ? 1 : 2) : 0;
-    act.scale = 1.0f / (float)(1.0 - (double)p);
-    act.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
-    act.mask = mask; act.H = N; act.seed = seed; act.offset = offset; act.offset_dev = offset_dev;
-    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, &act);
 }
 
 // ---- range guard of the two-piece fp16 split ------------------------------------------------------------------------

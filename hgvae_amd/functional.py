@@ -92,6 +92,19 @@ def _agg_affine_launch(csr, n_rows, d, F, col_s, col_t, out):
         ev[1].record()
 
 
+def _agg_ind_launch(csr, n_rows, d, F, out, ind_col):
+    """Mean aggregation of d over ``csr`` with the has-neighbours indicator in pad column ``ind_col`` of ``out``."""
+    ev = _probe.add("agg", (n_rows, F, csr.col.numel())) if _probe is not None else None
+    if ev:
+        ev[0].record()
+    lr = csr.long_rows(n_rows)
+    _lib.call("hgv_agg_fwd_ind", csr.rowptr.data_ptr(), csr.col.data_ptr(), n_rows, d.data_ptr(), ld_of(d), F, out.data_ptr(),
+              ld_of(out), ind_col, lr.threshold, lr.rows.data_ptr(), lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0,
+              _lib.stream())
+    if ev:
+        ev[1].record()
+
+
 class _Aggregate(torch.autograd.Function):
     """out_i = (mean | sum) over in-neighbours j of x_j."""
 
@@ -149,14 +162,18 @@ class _WeightedAggregate(torch.autograd.Function):
 # levels whose normalisation is deferred to their consumers
 # --------------------------------------------------------------------------------------
 # A level is  y = projection(...) -> relu? -> dropout -> batch norm  and its output feeds further projections / mean
-# aggregations.  Inside :func:`deferred_levels` (the loss functions of the train loops enter it) the projection applies
-# relu -> dropout while it stores its tile, the level takes the column statistics of that matrix d and hands out a
-# :class:`Deferred` - d plus the two vectors of  out = d * s + t  - and the consumers fold s / t into their weights
-# (``_image_affine``), apply them to finished aggregation rows, and correct their weight gradients (``_wgrad``): the
-# normalised matrix is never written or read.  HGVAE_DEFER=0 switches the mechanism off (A/B measurements).
+# aggregations.  Inside :func:`deferred_levels` (the loss functions of the train loops enter it) the pass that takes the
+# column statistics overwrites y with d = dropout(relu(y)), and the level hands out a :class:`Deferred` - d plus the two
+# vectors of  out = d * s + t  - whose consumers fold s / t into their weights (``_image_affine``), apply them to finished
+# aggregation rows, and correct their weight gradients (``_wgrad``): the normalised matrix is never written or read (one
+# read and one write of the level's matrix instead of two reads and a write).  HGVAE_DEFER=0 switches it off (A/B runs).
 _DEFER_ENABLED = os.environ.get("HGVAE_DEFER", "1") != "0"
 DEFER_MIN_P = 0.2        # folding s / t into the weights turns  (d - mean) * rstd  into a difference of two sums; dropout
                          # with probability p bounds |mean| / std of d by sqrt((1 - p) / p), so nothing cancels for p >= 0.2
+DEFER_MIN_ROWS = int(os.environ.get("HGVAE_DEFER_MIN_ROWS", "65536"))
+# Below this many rows a level is bound by its launches, not by its bytes, and deferral adds two small ones per consumer
+# (the scaled image, the weight-gradient finish): measured on one MI355X, captured steps of 4 416 rows 0.73 -> 0.77 ms and
+# 70 825 rows 1.98 -> 1.96 ms, eager steps of 160 984 rows 4.95 -> 4.69 ms, of 1 283 529 rows 36.1 -> 35.3 ms.
 _defer = False
 
 
@@ -173,14 +190,6 @@ def deferred_levels(enabled: bool = True):
         yield
     finally:
         _defer = prev
-
-
-class ActSpec:
-    """relu? -> dropout(p) with its noise, for a projection to apply while it stores its output."""
-    __slots__ = ("relu", "p", "mask", "seed", "offset", "ctr")
-
-    def __init__(self, relu, p, mask, seed, offset, ctr):
-        self.relu, self.p, self.mask, self.seed, self.offset, self.ctr = bool(relu), float(p), mask, seed, offset, ctr
 
 
 class Deferred:
@@ -213,6 +222,10 @@ class Deferred:
     def dim(self):
         return self.d.dim()
 
+    def record_stream(self, stream) -> None:
+        for t in (self.d, self.s, self.mean, self.rstd):          # s and t share one buffer
+            t.record_stream(stream)
+
     def tensor(self) -> torch.Tensor:
         if self._out is None:
             self._out = _Materialize.apply(self.d, self.mean, self.rstd, self.gamma, self.beta)
@@ -242,38 +255,40 @@ def _affine_ok(n: int, k1: int, k2: int) -> bool:
     return _projection == "f16x3" and _split_image_floats(n, k1, k2, "f16x3") > 0
 
 
-def _act_ok(n: int, k1: int, k2: int) -> bool:
-    return _projection == "f16x3" and bool(_lib.load().hgv_gemm_nt16h_act_supported(n, k1, k2))
-
-
-def _image_affine(wa, aff_a, wb, aff_b, bias):
-    """(scaled-fp16 image of [wa diag(s_a) | wb diag(s_b)], bias + wa t_a + wb t_b); ``aff`` = (s, t) or None."""
-    n, k1 = wa.shape
+def _image_affine(wa, aff_a, wb, aff_b, bias, ind_a: bool = False):
+    """(scaled-fp16 image of [wa diag(s_a) | wb diag(s_b)], bias + wa t_a + wb t_b); ``aff`` = (s, t) or None.  With
+    ``ind_a`` operand a carries one more column than ``wa``, a {0, 1} indicator per row, and ``wa t_a`` becomes that
+    column's weight instead of a part of the bias."""
+    n, k1 = wa.size(0), wa.size(1) + (1 if ind_a else 0)
     k2 = wb.size(1) if wb is not None else 0
     buf = torch.empty(_split_image_floats(n, k1, k2, "f16x3"), dtype=torch.float32, device=wa.device)
     bias_out = torch.empty(n, dtype=torch.float32, device=wa.device)
     sa, ta = aff_a if aff_a is not None else (None, None)
     sb, tb = aff_b if aff_b is not None else (None, None)
     _lib.call("hgv_pack16h_weights_affine", wa.data_ptr(), wa.stride(0), wa.stride(1), k1, _lib.ptr(sa), _lib.ptr(ta),
-              _lib.ptr(wb), wb.stride(0) if wb is not None else 0, wb.stride(1) if wb is not None else 0, k2,
+              1 if ind_a else 0, _lib.ptr(wb), wb.stride(0) if wb is not None else 0, wb.stride(1) if wb is not None else 0, k2,
               _lib.ptr(sb), _lib.ptr(tb), n, _lib.ptr(bias), bias_out.data_ptr(), buf.data_ptr(), _lib.stream())
     return _Image("f16x3", buf), bias_out
 
 
 def _wgrad_finish(jobs, colsum, accumulate: bool) -> None:
-    """dst (+)= raw * s + colsum t^T for up to three ``(dst, raw, (s, t) or None)`` jobs in one launch."""
+    """dst (+)= raw * s + c t^T for up to three jobs in one launch.  A job is ``(dst, raw, (s, t) or None)`` with
+    c = ``colsum``, or ``(dst, raw, (s, t), c)`` with its own vector c (any stride)."""
     nj = len(jobs)
     vp_t, i64_t, i32_t = _ctypes_arrays(nj)
     D, R, S, T, CS = vp_t(), vp_t(), vp_t(), vp_t(), vp_t()
-    ldd, ldr = i64_t(), i64_t()
+    ldd, ldr, css = i64_t(), i64_t(), i64_t()
     N, K = i32_t(), i32_t()
-    for q, (d, r, aff) in enumerate(jobs):
+    for q, job in enumerate(jobs):
+        d, r, aff = job[0], job[1], job[2]
+        c = job[3] if len(job) > 3 else colsum
         if tuple(d.shape) != tuple(r.shape) or (d.size(1) > 1 and (d.stride(1) != 1 or r.stride(1) != 1)):
             raise _lib.HgvError(f"weight-gradient finish: {tuple(d.shape)} / {d.stride()} from {tuple(r.shape)} / {r.stride()}")
         D[q], R[q], ldd[q], ldr[q], N[q], K[q] = d.data_ptr(), r.data_ptr(), max(d.stride(0), d.size(1)), max(r.stride(0), r.size(1)), r.size(0), r.size(1)
+        css[q] = 1
         if aff is not None:
-            S[q], T[q], CS[q] = aff[0].data_ptr(), aff[1].data_ptr(), colsum.data_ptr()
-    _lib.call("hgv_wgrad_finish", nj, D, ldd, R, ldr, N, K, S, T, CS, 1 if accumulate else 0, _lib.stream())
+            S[q], T[q], CS[q], css[q] = aff[0].data_ptr(), aff[1].data_ptr(), c.data_ptr(), (c.stride(0) if c.numel() > 1 else 1)
+    _lib.call("hgv_wgrad_finish", nj, D, ldd, R, ldr, N, K, S, T, CS, css, 1 if accumulate else 0, _lib.stream())
 
 
 def _wgrad(g, ops, bias, want_bias: bool):
@@ -321,30 +336,34 @@ def _wgrad(g, ops, bias, want_bias: bool):
 
 
 class _BnStats(torch.autograd.Function):
-    """Column statistics of an activated matrix d (see :class:`Deferred`): returns one or two handles on d and the
-    vectors [s | t], mean, rstd; the backward pass is that of relu? -> dropout -> batch norm read off d."""
+    """relu? -> dropout -> column statistics of a level, in place: the buffer of ``y`` holds d = dropout(relu(y))
+    afterwards (see :class:`Deferred`).  Returns one or two handles on it and the vectors [s | t], mean, rstd; the backward
+    pass is that of relu? -> dropout -> batch norm, read off d.  The caller must own ``y`` (nothing else may need the
+    pre-activation: the projections of this module keep only their inputs)."""
 
     @staticmethod
-    def forward(ctx, d, gamma, beta, running_mean, running_var, relu, p, eps, momentum, tracked, fork):
-        n, h = d.shape
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum, tracked, fork):
+        n, h = y.shape
         if n < 2:
             raise ValueError("Expected more than 1 value per channel when training")
         lib = _lib.load()
-        ws = _workspace(lib.hgv_bn_act_ws(n, h), d.device, "bn")
+        ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
         hp = (h + 3) // 4 * 4
-        st = torch.empty(2, hp, dtype=torch.float32, device=d.device)
-        save_mean = torch.empty(h, dtype=torch.float32, device=d.device)
-        save_rstd = torch.empty(h, dtype=torch.float32, device=d.device)
-        _lib.call("hgv_bn_stats", d.data_ptr(), ld_of(d), n, h, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
-                  _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked), save_mean.data_ptr(),
-                  save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        st = torch.empty(2, hp, dtype=torch.float32, device=y.device)
+        save_mean = torch.empty(h, dtype=torch.float32, device=y.device)
+        save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
+        d = y.detach()                 # same storage: overwritten behind autograd's back (y has no other reader)
+        _lib.call("hgv_bn_stats_act", d.data_ptr(), ld_of(d), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
+                  _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
+                  _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+                  ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (bool(relu), float(p))
         ctx.save_for_backward(d, gamma, save_mean, save_rstd, beta)
         ctx.mark_non_differentiable(st, save_mean, save_rstd)
         ctx.set_materialize_grads(False)
         if fork:
-            return d.view_as(d), d.view_as(d), st, save_mean, save_rstd
-        return d.view_as(d), st, save_mean, save_rstd
+            return y.view_as(y), y.view_as(y), st, save_mean, save_rstd
+        return y.view_as(y), st, save_mean, save_rstd
 
     @staticmethod
     def backward(ctx, *grads):
@@ -354,7 +373,7 @@ class _BnStats(torch.autograd.Function):
         if g is None:
             g, g2 = g2, None
         if g is None:
-            return (None,) * 11
+            return (None,) * 15
         n, h = d.shape
         g = rowmajor(g)
         g2 = rowmajor(g2) if g2 is not None else None
@@ -373,31 +392,28 @@ class _BnStats(torch.autograd.Function):
                   ws.numel(), _lib.stream())
         if direct:
             dgamma = dbeta = None
-        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 8
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 12
 
 
-def bn_level(make_y, n_rows: int, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
-    """One level: ``make_y(act)`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` is called once, with an
-    :class:`ActSpec` when the level may be deferred (the producer applies it and tags its output) or None; the result is
-    a tensor, or a :class:`Deferred` (a pair of either with ``fork``)."""
-    if _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P and n_rows >= 2:
-        dev = bn.weight.device if bn.weight is not None else bn.running_mean.device
-        mask, seed, offset, ctr = current_noise().dropout((n_rows, bn.num_features), dev)
-        act = ActSpec(relu, p, mask, seed, offset, ctr)
-        y = make_y(act)
-        if getattr(y, "_hgv_act", None) is act:
-            momentum = bn.momentum if bn.momentum is not None else 0.1
-            rm, rv, tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
-            if on_branch_stream():         # see bn_act: the trunk may be updating the running statistics right now
-                stand_in = torch.zeros(2, y.size(1), dtype=torch.float32, device=y.device)
-                _branch_updates.append((bn, stand_in, momentum))
-                rm, rv, tracked = stand_in[0], stand_in[1], None
-            outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, bn.eps, momentum, tracked, fork)
-            st, mean, rstd = outs[-3], outs[-2], outs[-1]
-            made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias) for h in outs[:-3]]
-            return (made[0], made[1]) if fork else made[0]
-        return bn_act(plain(y), bn, relu, p, training, fork=fork, noise=(mask, seed, offset, ctr))
-    return bn_act(plain(make_y(None)), bn, relu, p, training, fork=fork)
+def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
+    """One level: ``make_y()`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` builds the pre-activation (a fresh
+    matrix that nothing else reads); the result is a tensor, or inside :func:`deferred_levels` a :class:`Deferred`
+    (a pair of either with ``fork``)."""
+    y = plain(make_y())
+    if _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P and y.dim() == 2 and y.size(0) >= max(2, DEFER_MIN_ROWS) \
+            and y.requires_grad and y.grad_fn is not None and is_vec4(y):
+        mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        rm, rv, tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
+        if on_branch_stream():         # see bn_act: the trunk may be updating the running statistics right now
+            stand_in = torch.zeros(2, y.size(1), dtype=torch.float32, device=y.device)
+            _branch_updates.append((bn, stand_in, momentum))
+            rm, rv, tracked = stand_in[0], stand_in[1], None
+        outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, mask, seed, offset, ctr, bn.eps, momentum, tracked, fork)
+        st, mean, rstd = outs[-3], outs[-2], outs[-1]
+        made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias) for h in outs[:-3]]
+        return (made[0], made[1]) if fork else made[0]
+    return bn_act(y, bn, relu, p, training, fork=fork)
 
 
 # --------------------------------------------------------------------------------------
@@ -690,10 +706,9 @@ def _assert_zero_pads(*operands) -> None:
             raise _lib.HgvError(f"projection operand of shape {tuple(t.shape)} (leading dimension {ld_of(t)}) has non-zero pad columns")
 
 
-def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, act: Optional["ActSpec"] = None) -> torch.Tensor:
+def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
-    xa / xb must already be in the padded layout.  With ``act`` (callers check :func:`_act_ok` first) the kernel stores
-    dropout(relu(out)) and the result carries the spec as ``_hgv_act``."""
+    xa / xb must already be in the padded layout."""
     m = xa.size(0)
     if _CHECK_PADS:
         _assert_zero_pads(xa, xb)
@@ -701,14 +716,7 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, act: Optional["ActSpec"] = N
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     if ev:
         ev[0].record()
-    if act is not None:
-        if img.kind != "f16x3":
-            raise _lib.HgvError("a fused activation needs the scaled-fp16 projection kernels")
-        _lib.call("hgv_gemm_nt16h_act", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb),
-                  ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0, img.a.data_ptr(),
-                  _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out), int(act.relu), float(act.p), _lib.ptr(act.mask),
-                  act.seed, act.offset, act.ctr, _lib.stream())
-    elif img.kind == "auto":
+    if img.kind == "auto":
         # one pass over the operands decides on the device; both products are enqueued and exactly one of them runs
         flag = _workspace(256, xa.device, "range_flag")
         a2 = (_lib.ptr(xb), ld_of(xb) if xb is not None else 0, xb.size(1) if xb is not None else 0)
@@ -925,11 +933,10 @@ def _weight_grad2(g, xa, wa, xb, wb, bias=None, want_bias: bool = False):
 
 class _DualLinear(torch.autograd.Function):
     """y = xa @ Wa^T + xb @ Wb^T + bias on the matrix-core kernels (xb / Wb / bias optional).  ``aff_a`` / ``aff_b``: the
-    (s, t) vectors of an operand that arrives un-normalised (see :class:`Deferred`); ``act``: relu -> dropout to apply to
-    the stored result (see :func:`bn_level`)."""
+    (s, t) vectors of an operand that arrives un-normalised (see :class:`Deferred`)."""
 
     @staticmethod
-    def forward(ctx, xa, wa, xb, wb, bias, aff_a=None, aff_b=None, act=None):
+    def forward(ctx, xa, wa, xb, wb, bias, aff_a=None, aff_b=None):
         _lib.require_cuda(xa, wa)
         if wa.size(0) > MAX_GEMM_N or wa.size(1) > MAX_GEMM_N or (wb is not None and wb.size(1) > MAX_GEMM_N):
             raise _lib.HgvError(f"projection widths above {MAX_GEMM_N} are not supported "
@@ -945,7 +952,7 @@ class _DualLinear(torch.autograd.Function):
             fwd, bias_f = _image_affine(wa, aff_a, wb if xb is not None else None, aff_b, bias)
         else:
             bias_f = bias
-        y = _gemm_nt(xa, fwd, xb, bias_f, wa.size(0), act)
+        y = _gemm_nt(xa, fwd, xb, bias_f, wa.size(0))
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, wa, xb, wb, bias)
@@ -967,17 +974,17 @@ class _DualLinear(torch.autograd.Function):
         gwa, gwb = gws[0], (gws[1] if ctx.has_b else None)
         if ctx.has_b and need[2]:
             gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
-        return gxa, gwa, gxb, gwb, gb, None, None, None
+        return gxa, gwa, gxb, gwb, gb, None, None
 
 
 class _ConcatLinear(torch.autograd.Function):
     """y = [xa | xb] @ W^T + bias for one weight W [n_out, Ka + Kb] (a decoder level fed by the
     concatenation of the running activation and a skip tensor, gvae/gvae_skipcon.py:92-100).  The
     concatenation is never built, and both halves of the weight gradient are written straight into
-    one [n_out, Ka + Kb] matrix.  ``aff_a`` / ``aff_b`` / ``act`` as in :class:`_DualLinear`."""
+    one [n_out, Ka + Kb] matrix.  ``aff_a`` / ``aff_b`` as in :class:`_DualLinear`."""
 
     @staticmethod
-    def forward(ctx, xa, xb, w, bias, aff_a=None, aff_b=None, act=None):
+    def forward(ctx, xa, xb, w, bias, aff_a=None, aff_b=None):
         _lib.require_cuda(xa, xb, w)
         ka, kb = xa.size(1), xb.size(1)
         if w.size(1) != ka + kb:
@@ -994,7 +1001,7 @@ class _ConcatLinear(torch.autograd.Function):
             fwd, bias_f = _image_affine(wa, aff_a, wb, aff_b, bias)
         else:
             bias_f = bias
-        y = _gemm_nt(xa, fwd, xb, bias_f, w.size(0), act)
+        y = _gemm_nt(xa, fwd, xb, bias_f, w.size(0))
         ctx.has_bias = bias is not None
         ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, xb, w, bias)
@@ -1039,7 +1046,7 @@ class _ConcatLinear(torch.autograd.Function):
                     gw = None
                 if direct:
                     gb = None
-        return gxa, gxb, gw, gb, None, None, None
+        return gxa, gxb, gw, gb, None, None
 
 
 def _unwrap(x, ok: bool):
@@ -1049,15 +1056,10 @@ def _unwrap(x, ok: bool):
     return x, None
 
 
-def concat_linear(xa, xb, w, bias=None, act=None):
-    n, ka, kb = w.size(0), xa.size(1), xb.size(1)
-    ok = _affine_ok(n, ka, kb)
+def concat_linear(xa, xb, w, bias=None):
+    ok = _affine_ok(w.size(0), xa.size(1), xb.size(1))
     (xa, aff_a), (xb, aff_b) = _unwrap(xa, ok), _unwrap(xb, ok)
-    use_act = act if act is not None and _act_ok(n, ka, kb) else None
-    y = _ConcatLinear.apply(xa, xb, w, bias, aff_a, aff_b, use_act)
-    if use_act is not None:
-        y._hgv_act = use_act
-    return y
+    return _ConcatLinear.apply(xa, xb, w, bias, aff_a, aff_b)
 
 
 class _SageConv(torch.autograd.Function):
@@ -1071,7 +1073,7 @@ class _SageConv(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, wl, bl, wr, graph: Graph, mean: bool, aff=None, act=None):
+    def forward(ctx, x, wl, bl, wr, graph: Graph, mean: bool, aff=None):
         _lib.require_cuda(x, wl, wr)
         n_out, n_in = wl.shape
         if max(n_out, n_in) > MAX_GEMM_N:
@@ -1093,8 +1095,16 @@ class _SageConv(torch.autograd.Function):
             _agg_launch(graph.by_dst, n, tr[:, :n_out], n_out, 1 if mean else 0, None, None, None, tr[:, n_out:], y)
             ctx.save_for_backward(x, wl, wr, bl)
         else:
+            # a deferred operand with a free pad column: the aggregation runs on d as on any matrix and leaves a
+            # has-neighbours indicator in the pad column, which the projection takes as one more input column with the
+            # weight wl t (mean_j(d_j s + t) = mean_j(d_j) s + t * indicator); without a pad column the aggregation
+            # applies s / t to its finished rows itself
+            ind = aff is not None and n_in % 4 != 0
             agg = new_padded(n, n_in, x.device, zero_pad=False)
-            if aff is not None:
+            if ind:
+                _agg_ind_launch(graph.by_dst, n, x, n_in, agg, n_in)
+                agg = agg.as_strided((n, n_in + 1), agg.stride(), agg.storage_offset())
+            elif aff is not None:
                 _agg_affine_launch(graph.by_dst, n, x, n_in, aff[0], aff[1], agg)      # the aggregate of d * s + t itself
             else:
                 _agg_launch(graph.by_dst, n, x, n_in, 1 if mean else 0, None, None, None, None, agg)
@@ -1107,11 +1117,14 @@ class _SageConv(torch.autograd.Function):
             else:
                 fwd, ctx.plt, ctx.prt = _images(fwd_spec, (wl, None, True) if gi else None, (wr, None, True) if gi else None)
             bias_f = bl
-            if aff is not None:
+            if ind:
+                fwd, bias_f = _image_affine(wl, aff, wr, aff, bl, ind_a=True)      # [wl diag(s) | wl t | wr diag(s)], bl + wr t
+            elif aff is not None:
                 fwd, bias_f = _image_affine(wl, None, wr, aff, bl)         # [wl | wr diag(s)], bl + wr t
-            y = _gemm_nt(agg, fwd, x, bias_f, n_out, act)
+            y = _gemm_nt(agg, fwd, x, bias_f, n_out)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias, ctx.aff = graph, mean, first, bl is not None, aff
+        ctx.ind = (not first) and ind
         return y
 
     @staticmethod
@@ -1135,8 +1148,24 @@ class _SageConv(torch.autograd.Function):
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
-            # agg is the aggregate of the normalised operand itself: only the root operand x may be a stored d
-            (gwl, gwr), gb = _wgrad(g, [(agg, wl, None, need[1]), (x, wr, ctx.aff, need[3])], bl, want_bias)
+            if ctx.ind:
+                # operands [mean(d) | indicator] and d: raw products, then  raw * s + c t^T  with c = the indicator column
+                # of the first product (the sum of g over the rows that have neighbours) / the column sums of g
+                ra, rb, colsum = _gemm_tn2(g, agg, x, True)
+                bufs = [_grad_buffer(wl), _grad_buffer(wr), _grad_buffer(bl) if want_bias else None]
+                direct = bufs[0] is not None and bufs[1] is not None and (not want_bias or bufs[2] is not None)
+                gwl, gwr = (bufs[0], bufs[1]) if direct else (torch.empty_like(wl), torch.empty_like(wr))
+                jobs = [(gwl, ra[:, :n_in], ctx.aff, ra[:, n_in]), (gwr, rb, ctx.aff, colsum)]
+                gb = None
+                if want_bias:
+                    gb = bufs[2] if direct else torch.empty_like(colsum)
+                    jobs.append((gb.view(-1, 1), colsum.view(-1, 1), None))
+                _wgrad_finish(jobs, colsum, accumulate=direct)
+                if direct:
+                    gwl = gwr = gb = None
+            else:
+                # agg is the aggregate of the normalised operand itself: only the root operand x may be a stored d
+                (gwl, gwr), gb = _wgrad(g, [(agg, wl, None, need[1]), (x, wr, ctx.aff, need[3])], bl, want_bias)
             if need[0] and ctx.pt is not None:
                 gt = new_padded(n, n_out, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
@@ -1146,7 +1175,7 @@ class _SageConv(torch.autograd.Function):
                 gr = _gemm_nt(g, ctx.prt, None, None, n_in)
                 gx = new_padded(n, n_in, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, t, n_in, 0, None, None, inv, gr, gx)
-        return gx, gwl, gb, gwr, None, None, None, None
+        return gx, gwl, gb, gwr, None, None, None
 
 
 class _Fork(torch.autograd.Function):
@@ -1178,29 +1207,20 @@ def fork(x: torch.Tensor):
     return _Fork.apply(x)
 
 
-def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True, act=None):
+def sage_conv(x, graph: Graph, wl, bl, wr, mean: bool = True):
     if x.size(0) != graph.num_nodes:
         raise _lib.HgvError(f"x has {x.size(0)} rows but the graph has {graph.num_nodes} nodes")
     n_out, n_in = wl.shape
     first = n_out < n_in and 2 * n_out <= MAX_GEMM_N
     ok = mean and (_affine_ok(2 * n_out, n_in, 0) if first else _affine_ok(n_out, n_in, n_in))
     x, aff = _unwrap(x, ok)
-    use_act = act if act is not None and not first and _act_ok(n_out, n_in, n_in) else None
-    y = _SageConv.apply(x, wl, bl, wr, graph, mean, aff, use_act)
-    if use_act is not None:
-        y._hgv_act = use_act
-    return y
+    return _SageConv.apply(x, wl, bl, wr, graph, mean, aff)
 
 
-def dual_linear(xa, wa, xb=None, wb=None, bias=None, act=None):
-    n, ka, kb = wa.size(0), wa.size(1), (wb.size(1) if (xb is not None and wb is not None) else 0)
-    ok = _affine_ok(n, ka, kb)
+def dual_linear(xa, wa, xb=None, wb=None, bias=None):
+    ok = _affine_ok(wa.size(0), wa.size(1), wb.size(1) if (xb is not None and wb is not None) else 0)
     (xa, aff_a), (xb, aff_b) = _unwrap(xa, ok), (_unwrap(xb, ok) if xb is not None else (None, None))
-    use_act = act if act is not None and _act_ok(n, ka, kb) else None
-    y = _DualLinear.apply(xa, wa, xb, wb, bias, aff_a, aff_b, use_act)
-    if use_act is not None:
-        y._hgv_act = use_act
-    return y
+    return _DualLinear.apply(xa, wa, xb, wb, bias, aff_a, aff_b)
 
 
 # --------------------------------------------------------------------------------------

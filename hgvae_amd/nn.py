@@ -38,10 +38,9 @@ class SAGEConv(nn.Module):
         _kaiming_linear_(self.lin_l)
         _kaiming_linear_(self.lin_r)
 
-    def forward(self, x: torch.Tensor, edge_index, act=None) -> torch.Tensor:
-        """``act`` (internal): relu -> dropout for the projection to apply to its stored result (``Fn.bn_level``)."""
+    def forward(self, x: torch.Tensor, edge_index) -> torch.Tensor:
         g = graph_of(edge_index, x.size(0))
-        return Fn.sage_conv(x, g, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, mean=True, act=act)
+        return Fn.sage_conv(x, g, self.lin_l.weight, self.lin_l.bias, self.lin_r.weight, mean=True)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, aggr=mean"

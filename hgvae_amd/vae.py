@@ -78,15 +78,15 @@ class _VAEBase(nn.Module):
 
     def _sage_level(self, seq, x, g, fork: bool = False):
         conv, drop, bn = seq[0], seq[1], seq[2]
-        return Fn.bn_level(lambda act: conv(x, g, act=act), x.size(0), bn, True, drop.p, self.training, fork=fork)
+        return Fn.bn_level(lambda: conv(x, g), bn, True, drop.p, self.training, fork=fork)
 
     def _linear_level(self, xa, xb, lin, dropout, bn, relu: bool):
         """Decoder level: Linear over xa (or over [xa | xb]) -> (relu) -> dropout -> batch norm."""
         if xb is None:
-            make = lambda act: Fn.dual_linear(xa, lin.weight, None, None, lin.bias, act=act)      # noqa: E731
+            make = lambda: Fn.dual_linear(xa, lin.weight, None, None, lin.bias)       # noqa: E731
         else:
-            make = lambda act: Fn.concat_linear(xa, xb, lin.weight, lin.bias, act=act)            # noqa: E731
-        return Fn.bn_level(make, xa.size(0), bn, relu, dropout.p if dropout is not None else 0.0, self.training)
+            make = lambda: Fn.concat_linear(xa, xb, lin.weight, lin.bias)             # noqa: E731
+        return Fn.bn_level(make, bn, relu, dropout.p if dropout is not None else 0.0, self.training)
 
     def reparameterize(self, mean, log_std):
         ml = join_head(mean, log_std)

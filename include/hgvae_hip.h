@@ -334,30 +334,31 @@ int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64
 
 /* ---- levels whose normalisation is deferred to the consumers -----------------------------------------------------
  * A level of the reference is  y = conv-or-Linear(x) -> relu? -> Dropout -> BatchNorm1d  and the result feeds the next
- * SAGEConv / Linear (gvae/gvae_skipcon.py:105-118, :122-136).  Instead of writing y, then the normalised matrix, the
- * producing projection applies relu -> dropout while it stores its tile (hgv_gemm_nt16h_act: the matrix between the two
- * holds d = dropout(relu(y)); without a relu a dropped element is -0.0f, a kept zero +0.0f), hgv_bn_stats takes the
- * column statistics of d and returns the normalisation as two vectors (out = d * col_s + col_t), and the consumers use
- * d with them: hgv_pack16h_weights_affine folds them into the weight image and bias of a following projection,
- * hgv_agg_fwd_affine applies them to the finished rows of a mean aggregation, hgv_wgrad_finish corrects a weight gradient
- * that was formed with d in place of the normalised operand (G^T x = (G^T d) diag(s) + colsum(G) t^T).  hgv_bn_apply
- * writes the normalised matrix for a consumer that needs it after all; hgv_bn_act_bwd_pre is hgv_bn_act_bwd reading d
- * (its dy is the gradient of the projection's output before the activation).  hgv_gemm_nt16h_act_supported: 1 for the
- * shapes whose image has one part (resident or streamed). */
-int hgv_gemm_nt16h_act_supported(int N, int K1, int K2);
-int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
-                       const float* bias, int64_t M, int N, float* C, int64_t ldc, int relu, float p, const uint8_t* mask,
-                       uint64_t seed, uint64_t offset, const uint64_t* offset_dev, hgv_stream_t stream);
+ * SAGEConv / Linear (gvae/gvae_skipcon.py:105-118, :122-136).  hgv_bn_stats_act overwrites y with d = dropout(relu(y))
+ * (without a relu a dropped element is -0.0f, a kept zero +0.0f) in the pass that takes the column statistics of d and
+ * returns the normalisation as two vectors (out = d * col_s + col_t); the consumers then use d with them:
+ * hgv_pack16h_weights_affine folds them into the weight image and bias of a following projection, hgv_agg_fwd_affine
+ * applies them to the finished rows of a mean aggregation, hgv_wgrad_finish corrects a weight gradient that was formed
+ * with d in place of the normalised operand (G^T x = (G^T d) diag(s) + colsum(G) t^T).  The normalised matrix is never
+ * written; hgv_bn_apply writes it for a consumer that needs it after all.  hgv_bn_act_bwd_pre is hgv_bn_act_bwd reading d
+ * (relu and dropout are read off the stored values). */
+int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask, uint64_t seed,
+                     uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
+                     float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
+                     float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* cs1, const float* ct1,
-                               const float* W2, int64_t sn2, int64_t sk2, int K2, const float* cs2, const float* ct2, int N,
-                               const float* bias_in, float* bias_out, void* out, hgv_stream_t stream);
+                               int indicator1, const float* W2, int64_t sn2, int64_t sk2, int K2, const float* cs2,
+                               const float* ct2, int N, const float* bias_in, float* bias_out, void* out, hgv_stream_t stream);
+/* mean aggregation that also writes a has-neighbours indicator (1.0f / 0.0f) into the pad column ind_col of every output
+ * row: mean_j(d_j s + t) = mean_j(d_j) s + t * indicator, so [mean(d) | indicator] is the operand of a projection whose
+ * image holds [W diag(s) | W t] (indicator1 of hgv_pack16h_weights_affine) */
+int hgv_agg_fwd_ind(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* d, int64_t ldd, int F, float* out,
+                    int64_t ldo, int ind_col, int threshold, const int32_t* long_rows, const int32_t* long_count, int long_cap,
+                    int run_long_pass, hgv_stream_t stream);
 int hgv_agg_fwd_affine(const int32_t* rowptr, const int32_t* col, int64_t n_rows, const float* a, int64_t lda, int F,
                        const float* col_s, const float* col_t, float* out, int64_t ldo, int threshold,
                        const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
                        hgv_stream_t stream);
-int hgv_bn_stats(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
-                 float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
-                 float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_bn_apply(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, const float* save_mean,
                  const float* save_rstd, float* out, int64_t ldo, hgv_stream_t stream);
 int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* d, int64_t ldd, int64_t N,
@@ -366,7 +367,7 @@ int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg
                        hgv_stream_t stream);
 int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* lddst, const float* const* raw, const int64_t* ldraw,
                      const int* N, const int* K, const float* const* s, const float* const* t, const float* const* colsum,
-                     int accumulate, hgv_stream_t stream);
+                     const int64_t* cs_stride, int accumulate, hgv_stream_t stream);
 
 /* Range guard of the two-piece fp16 split (no counterpart in the reference: it serves the "auto" projection arithmetic of
  * the lin_l / lin_r / Linear products, gvae/gvae_skipcon.py:61-100).  hgv_row_range_flag sets flag[0] (device int) to 1

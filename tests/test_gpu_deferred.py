@@ -9,6 +9,13 @@ from graphs import path_batch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _defer_at_every_size(monkeypatch):
+    """Production defers levels from 65 536 rows upwards (smaller ones are launch-bound); the tests use it at every size."""
+    from hgvae_amd import functional as Fn
+    monkeypatch.setattr(Fn, "DEFER_MIN_ROWS", 0)
+
+
 def dev():
     return torch.device("cuda:0")
 
@@ -17,133 +24,114 @@ def _rand(shape, gen, scale=1.0):
     return torch.randn(*shape, device=dev(), generator=gen) * scale
 
 
-@pytest.mark.parametrize("m,k1,k2,n", [(37, 60, 0, 138), (1000, 138, 138, 138), (515, 28, 0, 138), (300, 138, 138, 56),
-                                       (4099, 105, 105, 138), (700, 256, 256, 256), (64, 12, 0, 32)])
-@pytest.mark.parametrize("relu", [True, False])
-def test_projection_with_fused_activation_explicit_mask(m, k1, k2, n, relu):
-    """hgv_gemm_nt16h_act with an explicit keep mask = dropout(relu(plain product)); without a relu the dropped entries
-    are negative zeros and kept zeros positive ones."""
-    from hgvae_amd import functional as Fn
-    if not Fn._act_ok(n, k1, k2):
-        pytest.skip("image of two parts: no fused activation for this shape")
-    gen = torch.Generator(device=dev()).manual_seed(m + n)
-    xa, xb = Fn.as_padded(_rand((m, k1), gen)), (Fn.as_padded(_rand((m, k2), gen)) if k2 else None)
-    wa, wb = _rand((n, k1), gen, 0.1), (_rand((n, k2), gen, 0.1) if k2 else None)
-    bias = _rand((n,), gen, 0.1)
-    p = 0.5
-    mask = (torch.rand(m, n, device=dev(), generator=gen) >= p).to(torch.uint8)
-    img = Fn._image(wa, wb, False)
-    assert img.kind == "f16x3"
-    y = Fn._gemm_nt(xa, img, xb, bias, n)
-    act = Fn.ActSpec(relu, p, mask, 0, 0, None)
-    d = Fn._gemm_nt(xa, img, xb, bias, n, act)
-    want = (torch.relu(y) if relu else y) * 2.0 * mask
-    assert torch.equal(d[:, :n] == 0, want[:, :n] == 0)
-    assert torch.equal(d[:, :n].abs(), want[:, :n].abs())                 # same bits up to the sign of zeros
-    neg_zero = (d[:, :n].view(torch.int32) == -2 ** 31)
-    if relu:
-        assert not bool(neg_zero.any())
-    else:
-        assert torch.equal(neg_zero, mask == 0)
-    if d.stride(0) > n:                                                   # pad columns stay zero
-        pads = d.as_strided((m, d.stride(0) - n), (d.stride(0), 1), d.storage_offset() + n)
-        assert float(pads.abs().max()) == 0.0
+class _PaddedCopy(torch.autograd.Function):
+    """A fresh matrix in the padded layout holding x; the identity for autograd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from hgvae_amd.graph import new_padded
+        out = new_padded(x.size(0), x.size(1), x.device)
+        out.copy_(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
-def test_projection_with_fused_activation_philox():
-    """Counter-based keep decisions: reproducible for one (seed, offset), different for another, keep rate 1 - p, and
-    unrelated between neighbouring rows / column groups."""
-    from hgvae_amd import functional as Fn
-    m, k, n, p = 20000, 138, 138, 0.49
-    gen = torch.Generator(device=dev()).manual_seed(3)
-    xa, w = Fn.as_padded(_rand((m, k), gen)), _rand((n, k), gen, 0.1)
-    img = Fn._image(w, None, False)
-    y = Fn._gemm_nt(xa, img, None, None, n)
-    ctr = torch.zeros(1, dtype=torch.int64, device=dev())
-
-    def run(seed, offset):
-        return Fn._gemm_nt(xa, img, None, None, n, Fn.ActSpec(False, p, None, seed, offset, ctr.data_ptr()))
-
-    a, b, c = run(7, 1 << 20), run(7, 1 << 20), run(7, 2 << 20)
-    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
-    kept_a, kept_c = a[:, :n].view(torch.int32) != -2 ** 31, c[:, :n].view(torch.int32) != -2 ** 31
-    assert not torch.equal(kept_a, kept_c)
-    rate = float(kept_a.float().mean())
-    assert abs(rate - (1 - p)) < 3e-3, rate
-    scale = 1.0 / (1.0 - p)
-    ref = y[:, :n] * torch.tensor(scale, dtype=torch.float32)
-    assert torch.equal(a[:, :n][kept_a], ref[kept_a])
-    col_rate = kept_a.float().mean(0)
-    assert float((col_rate - (1 - p)).abs().max()) < 0.02                  # every column sees the same probability
-    agree = (kept_a[:, :-1] == kept_a[:, 1:]).float().mean()
-    assert abs(float(agree) - (p * p + (1 - p) ** 2)) < 5e-3               # neighbouring columns are independent
-    ctr.fill_(1 << 33)
-    assert not torch.equal(kept_a, run(7, 1 << 20)[:, :n].view(torch.int32) != -2 ** 31)    # the device counter moves the stream
-
-
-@pytest.mark.parametrize("n,h", [(64, 12), (4416, 138), (70001, 138), (1000, 256), (333, 31)])
-def test_statistics_of_an_activated_matrix_equal_the_plain_level(n, h):
-    """hgv_bn_stats / hgv_bn_apply on d = dropout(relu(y)) give bit for bit what hgv_bn_act_fwd gives on y with the same
-    mask; col_s / col_t reproduce the normalisation as one multiply-add."""
-    from hgvae_amd import functional as Fn
-    gen = torch.Generator(device=dev()).manual_seed(n + h)
-    y = Fn.as_padded(_rand((n, h), gen))
+def _bn(h, gen):
     bn = torch.nn.BatchNorm1d(h).to(dev()).train()
     with torch.no_grad():
         bn.weight.copy_(torch.rand(h, device=dev(), generator=gen) + 0.5)
         bn.bias.copy_(_rand((h,), gen, 0.1))
+    return bn
+
+
+def _stats(y, bn, relu, p, noise, fork=False, running=True):
+    from hgvae_amd import functional as Fn
+    mask, seed, offset, ctr = noise
+    rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if running else (None, None, None)
+    return Fn._BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, mask, seed, offset, ctr, bn.eps, 0.1, nbt, fork)
+
+
+@pytest.mark.parametrize("n,h", [(64, 12), (4416, 138), (70001, 138), (1000, 256), (333, 31)])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("noise_kind", ["mask", "philox"])
+def test_in_place_activation_and_statistics_equal_the_plain_level(n, h, relu, noise_kind):
+    """hgv_bn_stats_act leaves d = dropout(relu(y)) in y's place (dropped entries negative zeros when there is no relu, kept
+    zeros positive) and hgv_bn_apply on it gives bit for bit what hgv_bn_act_fwd gives on y with the same noise: same
+    statistics, same running buffers; col_s / col_t reproduce the normalisation as one multiply-add."""
+    from hgvae_amd import functional as Fn
+    gen = torch.Generator(device=dev()).manual_seed(n + h)
+    y = Fn.as_padded(_rand((n, h), gen))
+    y[::5, ::3] = 0.0
+    bn = _bn(h, gen)
     bn2 = torch.nn.BatchNorm1d(h).to(dev()).train()
     bn2.load_state_dict(bn.state_dict())
     p = 0.5
     mask = (torch.rand(n, h, device=dev(), generator=gen) >= p).to(torch.uint8)
-    out = Fn.bn_act(y, bn, True, p, True, noise=(mask, 0, 0, None))
-    d = Fn.new_padded(n, h, dev())
-    d.copy_(torch.relu(y) * 2.0 * mask)
-    outs = Fn._BnStats.apply(d, bn2.weight, bn2.bias, bn2.running_mean, bn2.running_var, True, p, bn2.eps, 0.1,
-                             bn2.num_batches_tracked, False)
-    handle, st, mean, rstd = outs
+    noise = (mask, 0, 0, None) if noise_kind == "mask" else (None, 77, 3 << 20, None)
+    out = Fn.bn_act(y, bn, relu, p, True, noise=noise)
+    yc = Fn.new_padded(n, h, dev())
+    yc.copy_(y)
+    handle, st, mean, rstd = _stats(yc, bn2, relu, p, noise)
     got = Fn.Deferred(handle, st[0], st[1], mean, rstd, bn2.weight, bn2.bias).tensor()
     assert torch.equal(got, out)
     assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
     assert int(bn2.num_batches_tracked) == 1
+    d = handle.detach()
+    assert d.data_ptr() == yc.data_ptr()                                  # in place
+    act = torch.relu(y) if relu else y
+    neg_zero = d.view(torch.int32) == -2 ** 31
+    if noise_kind == "mask":
+        want = act * 2.0 * mask
+        assert torch.equal(d.abs(), want.abs())
+        if relu:
+            assert not bool(neg_zero.any())
+        else:
+            assert torch.equal(neg_zero, mask == 0)
+    else:
+        kept = ~neg_zero if not relu else None
+        if kept is not None:
+            assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+            assert torch.equal(d[kept], (act * 2.0)[kept])
     folded = d.double() * st[0, :h].double() + st[1, :h].double()
-    assert float((folded - out.double()).abs().max()) <= 2e-6 * max(float(out.abs().max()), 1.0)
-    assert float(st[:, h:].abs().max()) == 0.0 if st.size(1) > h else True
+    assert float((folded - out.detach().double()).abs().max()) <= 2e-6 * max(float(out.detach().abs().max()), 1.0)
+    if st.size(1) > h:
+        assert float(st[:, h:].abs().max()) == 0.0
 
 
-def test_backward_of_an_activated_level_equals_the_plain_level():
-    """hgv_bn_act_bwd_pre reads relu / dropout off the stored values: same dy, dgamma, dbeta as hgv_bn_act_bwd on y with the
-    mask, with and without a relu and with a second incoming gradient."""
+@pytest.mark.parametrize("relu", [True, False])
+def test_backward_of_a_deferred_level_equals_the_plain_level(relu):
+    """hgv_bn_act_bwd_pre reads relu / dropout off the stored values: same dy, dgamma, dbeta, bit for bit, as
+    hgv_bn_act_bwd on y with the mask - with a second incoming gradient and with exact zeros in y."""
     from hgvae_amd import functional as Fn
     n, h, p = 5000, 138, 0.5
     gen = torch.Generator(device=dev()).manual_seed(9)
-    for relu in (True, False):
-        y = Fn.as_padded(_rand((n, h), gen)).requires_grad_(True)
-        y.data[::7, ::3] = 0.0                                     # exact zeros: kept ones must not look dropped
-        mask = (torch.rand(n, h, device=dev(), generator=gen) >= p).to(torch.uint8)
-        g1, g2 = _rand((n, h), gen), _rand((n, h), gen)
-        bn = torch.nn.BatchNorm1d(h).to(dev()).train()
-        with torch.no_grad():
-            bn.weight.copy_(torch.rand(h, device=dev(), generator=gen) + 0.5)
-        oa, ob = Fn.bn_act(y, bn, relu, p, True, fork=True, noise=(mask, 0, 0, None))
-        (oa * g1).sum().add((ob * g2).sum()).backward()
-        want = (y.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone())
+    src = _rand((n, h), gen)
+    src[::7, ::3] = 0.0                                            # exact zeros: kept ones must not look dropped
+    mask = (torch.rand(n, h, device=dev(), generator=gen) >= p).to(torch.uint8)
+    g1, g2 = _rand((n, h), gen), _rand((n, h), gen)
+    bn = _bn(h, gen)
+    res = []
+    for deferred in (False, True):
+        leaf = src.clone().requires_grad_(True)
+        y = _PaddedCopy.apply(leaf)
         bn.zero_grad()
-        act = torch.relu(y.detach()) if relu else y.detach()
-        dm = act * 2.0
-        dm = torch.where(dm == 0, torch.zeros_like(dm), dm)        # kept zeros are +0
-        d = Fn.new_padded(n, h, dev())
-        d.copy_(torch.where(mask.bool(), dm, torch.full_like(dm, 0.0 if relu else -0.0)))
-        d.requires_grad_(True)
-        outs = Fn._BnStats.apply(d, bn.weight, bn.bias, None, None, relu, p, bn.eps, 0.1, None, True)
-        (outs[0] * g1).sum().add((outs[1] * g2).sum()).backward()
-        # the two handles stand for `out`: what flows back is taken as d(out), so weight them with s: the plain path's
-        # incoming gradients were those of out = d * s + t as well
-        assert torch.equal(d.grad, want[0]) and torch.equal(bn.weight.grad, want[1]) and torch.equal(bn.bias.grad, want[2])
+        if deferred:
+            outs = _stats(y, bn, relu, p, (mask, 0, 0, None), fork=True, running=False)
+            oa, ob = outs[0], outs[1]
+        else:
+            oa, ob = Fn.bn_act(y, bn, relu, p, True, fork=True, noise=(mask, 0, 0, None))
+        # both paths receive the gradients of `out`: by convention that is what flows into a deferred level's handles
+        torch.autograd.backward([oa, ob], [g1, g2])
+        res.append((leaf.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("first", [False, True])
-def test_sage_convolution_on_a_deferred_operand(first):
+@pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
+def test_sage_convolution_on_a_deferred_operand(first, h_in):
     """SAGEConv over (d, s, t) = SAGEConv over the written-out d * s + t: forward, input gradient (with respect to `out`),
     both weight gradients and the bias gradient, to fp32 rounding."""
     from hgvae_amd import functional as Fn
@@ -154,7 +142,7 @@ def test_sage_convolution_on_a_deferred_operand(first):
     ei = torch.cat([ei, extra], 1).to(dev())
     g = graph_of(ei, n)
     dgen = torch.Generator(device=dev()).manual_seed(22)
-    h_in, h_out = 138, (56 if first else 138)
+    h_out = 56 if first else 138
     d0 = torch.relu(_rand((n, h_in), dgen)) * (torch.rand(n, h_in, device=dev(), generator=dgen) > 0.5) * 2.0
     bn = torch.nn.BatchNorm1d(h_in).to(dev()).train()
     with torch.no_grad():
@@ -168,7 +156,7 @@ def test_sage_convolution_on_a_deferred_operand(first):
         d = Fn.new_padded(n, h_in, dev())
         d.copy_(d0)
         d.requires_grad_(True)
-        outs = Fn._BnStats.apply(d, bn.weight, bn.bias, None, None, True, 0.5, bn.eps, 0.1, None, False)
+        outs = _stats(_PaddedCopy.apply(d), bn, False, 0.0, (None, 0, 0, None), running=False)     # d as it is
         x = Fn.Deferred(outs[0], outs[1][0], outs[1][1], outs[2], outs[3], bn.weight, bn.bias)
         for t in (wl, wr, bl):
             t.grad = None
@@ -245,3 +233,31 @@ def test_train_step_with_deferred_levels_matches_the_plain_path(variant):
         assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale + 1e-7, (k, float((ga[k] - gb[k]).abs().max()), scale)
     for k in bb:
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("graph", ["paths", "random", "ragged", "edgeless"])
+def test_skipcon_step_with_deferred_levels_matches_the_oracle(graph):
+    """The oracle comparisons of tests/test_gpu_model.py, run with deferral at every size (the fixture of this file)."""
+    import test_gpu_model as M
+    M.test_skipcon_train_step_matches_oracle(graph)
+
+
+def test_other_variants_with_deferred_levels_match_the_oracle():
+    import test_gpu_golden as G
+    import test_gpu_model as M
+    M.test_skipcon_train_step_matches_float64_oracle_on_protein_like_batch()
+    for sizes in ([138] * 3, [1, 2, 90, 1]):
+        M.test_attention_train_step_matches_oracle(sizes)
+    for sizes in ([454, 200, 91], [1, 2, 77, 1, 3]):
+        M.test_pool_vae_train_step_and_pool_outputs_match_oracle(sizes)
+    for sizes in ([300, 154], [1, 61, 2, 1]):
+        M.test_custom_pool_vae_train_step_matches_oracle(sizes)
+    for tag in ("skipcon", "attention", "pool", "custom_pool"):
+        G.test_train_step_matches_golden(tag)
+
+
+def test_captured_step_with_deferred_levels_replays_and_learns():
+    import test_gpu_model as M
+    M.test_graphed_train_step_replays_with_fresh_noise_and_learns()
+    for variant in ("skipcon", "attention"):
+        M.test_captured_step_with_the_second_pass_on_a_branch_stream(variant)
