@@ -35,6 +35,15 @@ static inline size_t hgv_align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline int64_t hgv_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool hgv_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
+// Launches that keep progress hints in a static device array (paced kernels) take one of HGV_PACE_SLOTS copies of it,
+// chosen from the stream handle: launches that overlap on different streams then almost never share a copy (two handles
+// hash to one slot with probability 1 / HGV_PACE_SLOTS; the hints only cost time when they do, never correctness).
+#define HGV_PACE_SLOTS 8
+static inline int hgv_pace_slot(hipStream_t stream) {
+    const uintptr_t h = (uintptr_t)stream;
+    return (int)(((h >> 4) ^ (h >> 9) ^ (h >> 15)) % HGV_PACE_SLOTS);
+}
+
 // Workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD that
 // also runs b+8).  This maps the hardware block id to a logical id such that the
 // blocks sharing an XCD (and its private L2) cover one contiguous logical range.

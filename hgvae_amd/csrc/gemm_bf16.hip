@@ -152,6 +152,7 @@ struct Nt16Args {
     int64_t ntiles;            // 16-row tiles
     int wgs0;                  // two-part launches: workgroups [0, wgs0) work on part 0, the rest on part 1
     int paced;                 // two-part launches: twin waves of the two parts start every row tile together
+    int pace_slot;             // which copy of the progress counters a paced launch uses
     const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
 };
 #define HGV_GATE_EXIT16(a) if ((a).gate != nullptr && ((*(a).gate != 0) ? 1 : 0) != (a).gate_run_if) return
@@ -160,7 +161,7 @@ struct Nt16Args {
 // hints only (a stale or missing value costs time, never correctness), so launches may share them.
 constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
 constexpr int64_t PACE_MIN_BYTES = (int64_t)256 << 20;
-__device__ int pace_ctr[2 * PACE_WGS * PACE_WAVES];
+__device__ int pace_ctr[HGV_PACE_SLOTS * 2 * PACE_WGS * PACE_WAVES];
 
 // waves per workgroup: 16 while the registers allow 4 waves per SIMD (<= 128 VGPRs), 12 for the widest parts
 template <int NT> constexpr int nt16_waves() { return NT > 6 ? 12 : 16; }
@@ -223,8 +224,9 @@ __device__ __forceinline__ void nt16_body(const Nt16Args& a, unsigned char* lds_
     // memory again.  The twin's counter is read two steps before it is looked at (by then the wave waits for older
     // loads anyway), so the wave that is behind never waits for it; the one that is ahead polls.  A twin that does
     // not catch up within PACE_SPINS polls (not resident, other XCD) switches this wave's pacing off for the launch.
-    int* pace_mine = pace_ctr + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
-    const int* pace_twin = pace_ctr + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    int* pace_base = pace_ctr + a.pace_slot * (2 * PACE_WGS * PACE_WAVES);
+    int* pace_mine = pace_base + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    const int* pace_twin = pace_base + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
     bool pace = a.paced != 0;
     int pace_step = 0;                                // load groups issued by this wave
     int pace_seen[RING];                              // the twin's counter as read by the last RING load groups (slot = ring slot)
@@ -676,7 +678,7 @@ constexpr int T16_SET_FLOATS = 81 * 256;
 // Progress counters of paced weight-gradient launches, one per workgroup (64 bytes apart): 32-row steps finished.
 // Hints only, like pace_ctr above.
 constexpr int PACE_TN_AHEAD = 1;
-__device__ int pace_tn[PACE_WGS * 16];
+__device__ int pace_tn[HGV_PACE_SLOTS * PACE_WGS * 16];
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -692,6 +694,7 @@ struct Tn16Args {
     float* partial;            // [ngrp][kgrp][set][81][4][64]
     float* bias_partial;       // [ngrp][set][9][4][64], written by the workgroups of k group 0 (null: no bias)
     int paced;                 // two k groups, one n group: the two workgroups of a row slice share an XCD and walk G in step
+    int pace_slot;             // which copy of the progress counters a paced launch uses
 };
 
 __device__ __forceinline__ int t16_slot(int r) { return (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1); }
@@ -784,8 +787,8 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
     // behind, so that the later of the two reads of a G line finds it in the XCD's L2.  The twin's counter is loaded at
     // the top of a step and looked at after the step's MFMAs; a twin that does not catch up within PACE_SPINS polls
     // switches the pacing off for the rest of the launch.
-    int* pace_mine = pace_tn + blockIdx.x * 16;
-    const int* pace_twin = pace_tn + (blockIdx.x ^ 8) * 16;
+    int* pace_mine = pace_tn + (a.pace_slot * PACE_WGS + blockIdx.x) * 16;
+    const int* pace_twin = pace_tn + (a.pace_slot * PACE_WGS + (blockIdx.x ^ 8)) * 16;
     bool pace = a.paced != 0 && lead;
     for (int64_t s = s_lo; s < s_hi; ++s) {
         const int b = (int)((s - s_lo) & 1);
@@ -1007,8 +1010,8 @@ __device__ __forceinline__ void tn16h_body(const Tn16Args& a, unsigned char* lds
         if (s_lo + 2 < s_hi) load_step(s_lo + 2, 0);
     }
     __syncthreads();
-    int* pace_mine = pace_tn + blockIdx.x * 16;
-    const int* pace_twin = pace_tn + (blockIdx.x ^ 8) * 16;
+    int* pace_mine = pace_tn + (a.pace_slot * PACE_WGS + blockIdx.x) * 16;
+    const int* pace_twin = pace_tn + (a.pace_slot * PACE_WGS + (blockIdx.x ^ 8)) * 16;
     bool pace = a.paced != 0 && lead;
     // step s with PAR = (s - s_lo) & 1: tile s + 1 sits in register set PAR ^ 1, tile s + 2 in set PAR
     auto step = [&](int64_t s, const int PAR) __attribute__((always_inline)) {
@@ -1254,6 +1257,7 @@ static int gemm_nt16_any(const float* A1, int64_t lda1, int K1, const float* A2,
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const __bf16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
     a.gate = gate; a.gate_run_if = gate_run_if;
+    a.pace_slot = hgv_pace_slot(stream);
     const size_t lds = part_bytes16(a.g.tpp, a.g.chunks) + (size_t)a.g.chunks * 64 + 9 * 16 * 4;
     // a part holds exactly its n tiles; the rows of A are streamed once per part
     int rc;
@@ -1316,6 +1320,7 @@ static int gemm_tn16_any(bool f16, const float* G, int64_t ldg, int N, const flo
     a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.M = M; a.steps = p.steps; a.sets = p.sets;
     // pacing pays once G no longer stays in the memory-side cache between its two reads; it needs every workgroup resident
     // (one per CU) and whole groups of 16 blocks
+    a.pace_slot = hgv_pace_slot(stream);
     a.paced = (p.ngrps == 1 && p.kgrps == 2 && p.sets % 8 == 0 && 2 * p.sets <= PACE_WGS && 2 * p.sets <= cu_count16() &&
                M * ldg * 4 >= tn_pace_min_bytes()) ? 1 : 0;
     a.partial = (float*)ws;

@@ -175,6 +175,7 @@ struct NtHArgs {
     int64_t ntiles;
     int wgs0;
     int paced;
+    int pace_slot;                         // which copy of the progress counters a paced launch uses
     const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
 };
 
@@ -184,7 +185,7 @@ struct NtHArgs {
 // Progress counters of paced two-part launches (hints only: a stale value costs time, never correctness).
 constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
 constexpr int64_t PACE_MIN_BYTES = (int64_t)256 << 20;
-__device__ int pace_ctr_h[2 * PACE_WGS * PACE_WAVES];
+__device__ int pace_ctr_h[HGV_PACE_SLOTS * 2 * PACE_WGS * PACE_WAVES];
 
 #ifndef NTH_WAVES_WIDE
 #define NTH_WAVES_WIDE 12
@@ -279,8 +280,9 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     const int wlane_last = row_last * 64 + ((kq ^ ((row_last & 8) ? 3 : 0)) * 16);
 
     // pacing of two-part launches: see k_gemm_nt16_pair
-    int* pace_mine = pace_ctr_h + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
-    const int* pace_twin = pace_ctr_h + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    int* pace_base = pace_ctr_h + a.pace_slot * (2 * PACE_WGS * PACE_WAVES);
+    int* pace_mine = pace_base + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
+    const int* pace_twin = pace_base + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
     bool pace = a.paced != 0;
     int pace_step = 0;
     int pace_seen[RING];
@@ -799,6 +801,7 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     a.A1 = A1; a.lda1 = lda1; a.A2 = A2; a.lda2 = lda2; a.Wp = (const _Float16*)Wp; a.bias = bias;
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
     a.gate = gate; a.gate_run_if = gate_run_if;
+    a.pace_slot = hgv_pace_slot(stream);
     int rc;
     if (a.g.stream) {
         rc = launch_nths(a, stream);

@@ -207,3 +207,27 @@ def test_paced_two_part_product_at_hidden_width_256():
     assert rel(full[rows], want) <= 2e-6
     del full, x
     torch.cuda.empty_cache()
+
+
+def test_paced_products_on_two_streams_at_once():
+    """Paced launches keep their progress hints in a copy of the counters chosen from the stream handle, so two of them
+    running at the same time on two streams do not read each other's hints; either way the hints never decide a value:
+    both results equal the one-stream result bit for bit."""
+    from hgvae_amd import functional as Fn
+    m, h = 300_000, 256
+    gen = torch.Generator(device=DEV).manual_seed(10)
+    xs = [torch.randn(m, h, device=DEV, generator=gen) for _ in range(2)]
+    w = torch.randn(h, h, device=DEV, generator=gen) * 0.1
+    with torch.no_grad():
+        want = [Fn.dual_linear(x, w) for x in xs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(DEV) for _ in range(2)]
+        got = [None, None]
+        for rep in range(3):
+            for k, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    got[k] = Fn.dual_linear(xs[k], w)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    del xs, want, got
+    torch.cuda.empty_cache()
