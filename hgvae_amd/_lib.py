@@ -85,6 +85,8 @@ SIGNATURES = {
     "hgv_bn_apply": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "hgv_bn_act_bwd_pre": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _i64, _vp, _vp,
                                      _i32, _vp, _sz, _vp]),
+    "hgv_bn_act_bwd_pre_alg": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "hgv_wgrad_finish": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "hgv_row_range_flag": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _i32, _vp, _vp]),
     "hgv_gemm_nt16h_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),

@@ -900,6 +900,97 @@ extern "C" int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, 
     return HGV_OK;
 }
 
+// The same backward without the statistics pass.  When every consumer of the level is a projection (or a mean
+// aggregation feeding one) that received the level as (d, s, t), the incoming gradient is a sum of products
+//   g = sum_parts G_p W_p      (G_p: the consumer's own output gradient, or its transposed aggregate; W_p [n_p, H]),
+// and the two column sums the backward needs follow from matrices the consumers' weight-gradient products have
+// already formed - raw_p = G_p^T d [n_p, H] and csum_p = column sums of G_p [n_p]:
+//   sum_i g_ic      = sum_p sum_n W_p[n,c] csum_p[n],
+//   sum_i g_ic d_ic = sum_p sum_n W_p[n,c] raw_p[n,c],     sum_i g_ic xhat_ic = rstd_c (sum_i g_ic d_ic - mean_c sum_i g_ic).
+// A few hundred multiply-adds per column (float64) replace a pass over g, g2 and d.
+namespace {
+constexpr int ALG_MAX_PARTS = 4;
+struct AlgPart { const float* W; int64_t ldw; const float* raw; int64_t ldraw; const float* csum; int64_t cs_stride; int n; };
+struct AlgArgs {
+    AlgPart part[ALG_MAX_PARTS]; int nparts; int H, Hp;
+    const float* mean; const float* rstd;
+    float* sums; float* dgamma; float* dbeta; int accumulate;
+};
+__global__ __launch_bounds__(256) void k_ep_bwd_sums_alg(const AlgArgs a) {
+    __shared__ double sh1[8][33], sh2[8][33];
+    const int cl = threadIdx.x & 31, ng = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < a.H) {
+        for (int p = 0; p < a.nparts; ++p) {
+            const AlgPart& q = a.part[p];
+            for (int n0 = ng; n0 < q.n; n0 += 32) {             // four rows of W in flight per thread
+                float w[4], r[4], s[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = min(n0 + 8 * u, q.n - 1);
+                    w[u] = q.W[(int64_t)n * q.ldw + c]; r[u] = q.raw[(int64_t)n * q.ldraw + c]; s[u] = q.csum[(int64_t)n * q.cs_stride];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (n0 + 8 * u < q.n) { a1 += (double)w[u] * (double)s[u]; a2 += (double)w[u] * (double)r[u]; }
+                }
+            }
+        }
+    }
+    sh1[ng][cl] = a1; sh2[ng][cl] = a2;
+    __syncthreads();
+    if (ng == 0 && c < a.Hp) {
+        double s1 = 0.0, sd = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += sh1[u][cl]; sd += sh2[u][cl]; }
+        float f1 = 0.f, f2 = 0.f;
+        if (c < a.H) {
+            f1 = (float)s1;
+            f2 = (float)((double)a.rstd[c] * (sd - (double)a.mean[c] * s1));
+            if (a.dbeta) a.dbeta[c] = a.accumulate ? a.dbeta[c] + f1 : f1;
+            if (a.dgamma) a.dgamma[c] = a.accumulate ? a.dgamma[c] + f2 : f2;
+        }
+        a.sums[c] = f1; a.sums[a.Hp + c] = f2;
+    }
+}
+}  // namespace
+
+// hgv_bn_act_bwd_pre with the two column sums taken from the consumers' products (see above) instead of a pass over the
+// matrices: nparts <= 4 parts (W_p [n_p, H] with leading dimension ldw_p, raw_p [n_p, H] with ldraw_p, csum_p with element
+// stride cs_stride_p).  g (+ g2) must be exactly sum_p G_p W_p; dy, dgamma, dbeta as for hgv_bn_act_bwd_pre.
+extern "C" int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* d, int64_t ldd,
+                                      int64_t N, int H, int relu, float p, const float* gamma, const float* save_mean,
+                                      const float* save_rstd, int nparts, const float* const* W, const int64_t* ldw,
+                                      const float* const* raw, const int64_t* ldraw, const float* const* csum,
+                                      const int64_t* cs_stride, const int* n, float* dy, int64_t lddy, float* dgamma,
+                                      float* dbeta, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d, ldd, N, H, relu, p, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(g && ldg >= H && dy && lddy >= H && save_mean && save_rstd && ws && (!g2 || ldg2 >= H), HGV_EINVAL, "bn_act_bwd_pre_alg: null/short buffer");
+    HGV_REQUIRE(nparts >= 1 && nparts <= ALG_MAX_PARTS && W && ldw && raw && ldraw && csum && cs_stride && n, HGV_EINVAL,
+                "bn_act_bwd_pre_alg: 1..%d parts expected", ALG_MAX_PARTS);
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd_pre_alg: workspace too small or misaligned");
+    a.pre = 1; a.mode = 0;
+    const int Hp = a.CH * 4;
+    float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
+    AlgArgs q{};
+    q.nparts = nparts; q.H = H; q.Hp = Hp; q.mean = save_mean; q.rstd = save_rstd; q.sums = sums; q.dgamma = dgamma; q.dbeta = dbeta;
+    q.accumulate = accumulate;
+    for (int k = 0; k < nparts; ++k) {
+        HGV_REQUIRE(W[k] && raw[k] && csum[k] && n[k] > 0 && ldw[k] >= H && ldraw[k] >= H, HGV_EINVAL, "bn_act_bwd_pre_alg: bad part %d", k);
+        q.part[k] = AlgPart{W[k], ldw[k], raw[k], ldraw[k], csum[k], cs_stride[k], n[k]};
+    }
+    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, nullptr, 0, nullptr, 0};
+    const bool vec = vec4_ok(d, ldd, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(dy, lddy, Hp);
+    if (vec) hipLaunchKernelGGL((k_ep_bwd_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, b);
+    else hipLaunchKernelGGL((k_ep_bwd_apply<false, 1>), dim3(nb), dim3(256), 0, stream, a, b);
+    HGV_CHECK_LAUNCH("bn_act_bwd_pre_alg");
+    return HGV_OK;
+}
+
 // Weight-gradient finish for operands that were handed over un-normalised.  With x = a * s + t column by column,
 //   G^T x = (G^T a) diag(s) + colsum(G) t^T:
 // dst[n,k] (+)= raw[n,k] * s[k] + colsum[n * cs_stride] * t[k]   (s / t null: dst (+)= raw).  Up to three jobs per launch

@@ -175,6 +175,9 @@ DEFER_MIN_ROWS = int(os.environ.get("HGVAE_DEFER_MIN_ROWS", "65536"))
 # (the scaled image, the weight-gradient finish): measured on one MI355X, captured steps of 4 416 rows 0.73 -> 0.77 ms and
 # 70 825 rows 1.98 -> 1.96 ms, eager steps of 160 984 rows 4.95 -> 4.69 ms, of 1 283 529 rows 36.1 -> 35.3 ms.
 _defer = False
+# The backward pass of a deferred level takes its two column sums from the consumers' weight-gradient products when it
+# can (hgv_bn_act_bwd_pre_alg); HGVAE_ALG_SUMS=0 always takes them from the matrices (A/B runs).
+_alg_sums = os.environ.get("HGVAE_ALG_SUMS", "1") != "0"
 
 
 def set_deferred_levels(enabled: bool) -> None:
@@ -192,16 +195,36 @@ def deferred_levels(enabled: bool = True):
         _defer = prev
 
 
+class _GradParts:
+    """What the consumers of one deferred level leave behind for its backward pass.  A consumer that took the level as
+    (d, s, t) sends back g_p = G_p W_p and has, for its own weight gradient, formed raw_p = G_p^T d and the column sums
+    of G_p; with those of ALL consumers the level's backward needs no pass over the matrices to get the column sums of g
+    and of g * xhat (hgv_bn_act_bwd_pre_alg).  ``uses`` counts the consumers that registered in the forward pass;
+    ``tainted``: some consumer read the level another way (the written-out matrix, frozen weights, an aggregate of the
+    normalised operand), so the sums must be taken from the matrices."""
+    __slots__ = ("parts", "uses", "tainted")
+
+    def __init__(self):
+        self.parts, self.uses, self.tainted = [], 0, False
+
+    def add(self, w, raw, csum) -> None:
+        self.parts.append((w, raw, csum))
+
+    def complete(self) -> bool:
+        return not self.tainted and 0 < self.uses == len(self.parts) <= 4
+
+
 class Deferred:
     """Output of a level, kept as d = dropout(relu(y)) [N, H] and the column vectors s, t of  out = d * s + t.
 
     ``d`` is connected to the autograd graph; by convention the gradient that flows back into it is the gradient with
     respect to ``out`` (the consumers in this module compute exactly that).  ``tensor()`` writes ``out`` for a consumer
     that needs the matrix."""
-    __slots__ = ("d", "s", "t", "mean", "rstd", "gamma", "beta", "_out")
+    __slots__ = ("d", "s", "t", "mean", "rstd", "gamma", "beta", "parts", "_out")
 
-    def __init__(self, d, s, t, mean, rstd, gamma, beta):
+    def __init__(self, d, s, t, mean, rstd, gamma, beta, parts=None):
         self.d, self.s, self.t, self.mean, self.rstd, self.gamma, self.beta = d, s, t, mean, rstd, gamma, beta
+        self.parts = parts
         self._out = None
 
     @property
@@ -227,6 +250,8 @@ class Deferred:
             t.record_stream(stream)
 
     def tensor(self) -> torch.Tensor:
+        if self.parts is not None:
+            self.parts.tainted = True
         if self._out is None:
             self._out = _Materialize.apply(self.d, self.mean, self.rstd, self.gamma, self.beta)
         return self._out
@@ -263,12 +288,23 @@ def _image_affine(wa, aff_a, wb, aff_b, bias, ind_a: bool = False):
     k2 = wb.size(1) if wb is not None else 0
     buf = torch.empty(_split_image_floats(n, k1, k2, "f16x3"), dtype=torch.float32, device=wa.device)
     bias_out = torch.empty(n, dtype=torch.float32, device=wa.device)
-    sa, ta = aff_a if aff_a is not None else (None, None)
-    sb, tb = aff_b if aff_b is not None else (None, None)
+    sa, ta = (aff_a[0], aff_a[1]) if aff_a is not None else (None, None)
+    sb, tb = (aff_b[0], aff_b[1]) if aff_b is not None else (None, None)
     _lib.call("hgv_pack16h_weights_affine", wa.data_ptr(), wa.stride(0), wa.stride(1), k1, _lib.ptr(sa), _lib.ptr(ta),
               1 if ind_a else 0, _lib.ptr(wb), wb.stride(0) if wb is not None else 0, wb.stride(1) if wb is not None else 0, k2,
               _lib.ptr(sb), _lib.ptr(tb), n, _lib.ptr(bias), bias_out.data_ptr(), buf.data_ptr(), _lib.stream())
     return _Image("f16x3", buf), bias_out
+
+
+def _taint(aff) -> None:
+    if aff is not None and len(aff) > 2 and aff[2] is not None:
+        aff[2].tainted = True
+
+
+def _contribute(aff, w, raw, csum) -> None:
+    """Leave (W, G^T d, column sums of G) of a product with a deferred operand for that level's backward pass."""
+    if aff is not None and len(aff) > 2 and aff[2] is not None:
+        aff[2].add(w, raw, csum)
 
 
 def _wgrad_finish(jobs, colsum, accumulate: bool) -> None:
@@ -298,6 +334,9 @@ def _wgrad(g, ops, bias, want_bias: bool):
     x * s + t column by column (then G^T (x s + t) = (G^T x) diag(s) + colsum(G) t^T is formed from the raw product).
     Returns ([gw_i ...], gb) for autograd with None where a gradient was added straight into ``.grad`` or not wanted."""
     live = [(x, w, aff) for (x, w, aff, want) in ops if want]
+    for (_, _, aff, want) in ops:
+        if aff is not None and not want:
+            _taint(aff)                   # no product with this operand is formed: its level takes its sums the long way
     if not live:
         if want_bias:
             _, gb = _gemm_tn(g, ops[0][0], True)
@@ -317,6 +356,8 @@ def _wgrad(g, ops, bias, want_bias: bool):
         else:
             ra, colsum = _gemm_tn(g, live[0][0], True)
             raws = [ra]
+        for r, (_, w, aff) in zip(raws, live):
+            _contribute(aff, w, r, colsum)
         bufs = [_grad_buffer(w) for (_, w, _) in live]
         bbuf = _grad_buffer(bias) if want_bias else None
         direct = all(b is not None for b in bufs) and (not want_bias or bbuf is not None)
@@ -342,7 +383,9 @@ class _BnStats(torch.autograd.Function):
     pre-activation: the projections of this module keep only their inputs)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum, tracked, fork):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum, tracked, fork,
+                parts=None):
+        ctx.parts = parts
         n, h = y.shape
         if n < 2:
             raise ValueError("Expected more than 1 value per channel when training")
@@ -373,7 +416,7 @@ class _BnStats(torch.autograd.Function):
         if g is None:
             g, g2 = g2, None
         if g is None:
-            return (None,) * 15
+            return (None,) * 16
         n, h = d.shape
         g = rowmajor(g)
         g2 = rowmajor(g2) if g2 is not None else None
@@ -386,13 +429,31 @@ class _BnStats(torch.autograd.Function):
         direct = gbuf is not None and bbuf is not None
         dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
         dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
-        _lib.call("hgv_bn_act_bwd_pre", g.data_ptr(), ld_of(g), _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, d.data_ptr(),
-                  ld_of(d), n, h, int(relu), float(p), _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
-                  dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(),
-                  ws.numel(), _lib.stream())
+        parts = ctx.parts
+        if _alg_sums and parts is not None and parts.complete() and all(w.size(1) == h for (w, _, _) in parts.parts):
+            # every consumer was a projection on (d, s, t): the column sums come from their weight-gradient products
+            nparts = len(parts.parts)
+            vp_t, i64_t, i32_t = _ctypes_arrays(nparts)
+            W, R, CS = vp_t(), vp_t(), vp_t()
+            ldw, ldr, css = i64_t(), i64_t(), i64_t()
+            nn_ = i32_t()
+            for q, (w, raw, cs) in enumerate(parts.parts):
+                W[q], R[q], CS[q] = w.data_ptr(), raw.data_ptr(), cs.data_ptr()
+                ldw[q], ldr[q], css[q], nn_[q] = w.stride(0), raw.stride(0), (cs.stride(0) if cs.numel() > 1 else 1), w.size(0)
+            _lib.call("hgv_bn_act_bwd_pre_alg", g.data_ptr(), ld_of(g), _lib.ptr(g2), ld_of(g2) if g2 is not None else 0,
+                      d.data_ptr(), ld_of(d), n, h, int(relu), float(p), _lib.ptr(gamma), save_mean.data_ptr(),
+                      save_rstd.data_ptr(), nparts, W, ldw, R, ldr, CS, css, nn_, dy.data_ptr(), ld_of(dy), dgamma.data_ptr(),
+                      dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        else:
+            _lib.call("hgv_bn_act_bwd_pre", g.data_ptr(), ld_of(g), _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, d.data_ptr(),
+                      ld_of(d), n, h, int(relu), float(p), _lib.ptr(gamma), save_mean.data_ptr(), save_rstd.data_ptr(),
+                      dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(),
+                      ws.numel(), _lib.stream())
+        if parts is not None:
+            parts.parts.clear()
         if direct:
             dgamma = dbeta = None
-        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 12
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 13
 
 
 def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
@@ -409,9 +470,11 @@ def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: b
             stand_in = torch.zeros(2, y.size(1), dtype=torch.float32, device=y.device)
             _branch_updates.append((bn, stand_in, momentum))
             rm, rv, tracked = stand_in[0], stand_in[1], None
-        outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, mask, seed, offset, ctr, bn.eps, momentum, tracked, fork)
+        parts = _GradParts()
+        outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, mask, seed, offset, ctr, bn.eps, momentum, tracked, fork,
+                              parts)
         st, mean, rstd = outs[-3], outs[-2], outs[-1]
-        made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias) for h in outs[:-3]]
+        made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias, parts) for h in outs[:-3]]
         return (made[0], made[1]) if fork else made[0]
     return bn_act(y, bn, relu, p, training, fork=fork)
 
@@ -1019,6 +1082,9 @@ class _ConcatLinear(torch.autograd.Function):
         if need[1]:
             gxb = _gemm_nt(g, ctx.pbt, None, None, xb.size(1))
         want_bias = ctx.has_bias and need[3]
+        if not need[2]:
+            _taint(ctx.aff_a)
+            _taint(ctx.aff_b)
         if need[2] or want_bias:
             wbuf = _grad_buffer(w) if need[2] else None
             bbuf = _grad_buffer(bias) if want_bias else None
@@ -1034,6 +1100,8 @@ class _ConcatLinear(torch.autograd.Function):
             else:
                 # raw products with the stored operands, then  (G^T d) diag(s) + colsum(G) t^T  per half
                 ra, rb, colsum = _gemm_tn2(g, xa, xb, True)
+                _contribute(ctx.aff_a, w[:, :ka], ra, colsum)
+                _contribute(ctx.aff_b, w[:, ka:], rb, colsum)
                 if not direct:
                     gw = torch.empty_like(w, memory_format=torch.contiguous_format)
                     gb = torch.empty_like(colsum) if want_bias else None
@@ -1052,7 +1120,11 @@ class _ConcatLinear(torch.autograd.Function):
 def _unwrap(x, ok: bool):
     """(stored operand, (s, t) or None) of a projection input; a :class:`Deferred` the projection cannot fold is written out."""
     if isinstance(x, Deferred):
-        return (x.d, (x.s, x.t)) if ok else (x.tensor(), None)
+        if not ok:
+            return x.tensor(), None
+        if x.parts is not None:
+            x.parts.uses += 1
+        return x.d, (x.s, x.t, x.parts)
     return x, None
 
 
@@ -1143,6 +1215,8 @@ class _SageConv(torch.autograd.Function):
             _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
             (gwl,), _ = _wgrad(gt, [(x, wl, ctx.aff, need[1])], None, False)
             (gwr,), gb = _wgrad(g, [(x, wr, ctx.aff, need[3])], bl, want_bias)
+            if ctx.aff is not None and len(ctx.aff) > 2 and ctx.aff[2] is not None:
+                ctx.aff[2].uses += 1                      # one consumer, two parts (g_x = aggT(g) wl + g wr)
             if need[0]:
                 gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
         else:
@@ -1152,6 +1226,11 @@ class _SageConv(torch.autograd.Function):
                 # operands [mean(d) | indicator] and d: raw products, then  raw * s + c t^T  with c = the indicator column
                 # of the first product (the sum of g over the rows that have neighbours) / the column sums of g
                 ra, rb, colsum = _gemm_tn2(g, agg, x, True)
+                # g_x = aggT(g) wl + g wr, and aggT(g)^T d = g^T mean_agg(d), colsum(aggT(g)) = g^T indicator
+                _contribute(ctx.aff, wl, ra[:, :n_in], ra[:, n_in])
+                _contribute(ctx.aff, wr, rb, colsum)
+                if ctx.aff[2] is not None:
+                    ctx.aff[2].uses += 1                  # one consumer, two parts
                 bufs = [_grad_buffer(wl), _grad_buffer(wr), _grad_buffer(bl) if want_bias else None]
                 direct = bufs[0] is not None and bufs[1] is not None and (not want_bias or bufs[2] is not None)
                 gwl, gwr = (bufs[0], bufs[1]) if direct else (torch.empty_like(wl), torch.empty_like(wr))
@@ -1165,6 +1244,7 @@ class _SageConv(torch.autograd.Function):
                     gwl = gwr = gb = None
             else:
                 # agg is the aggregate of the normalised operand itself: only the root operand x may be a stored d
+                _taint(ctx.aff)                           # ... and g^T agg(out) says nothing about g^T d
                 (gwl, gwr), gb = _wgrad(g, [(agg, wl, None, need[1]), (x, wr, ctx.aff, need[3])], bl, want_bias)
             if need[0] and ctx.pt is not None:
                 gt = new_padded(n, n_out, g.device, zero_pad=False)

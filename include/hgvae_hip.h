@@ -365,6 +365,15 @@ int hgv_bn_act_bwd_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg
                        int H, int relu, float p, const float* gamma, const float* save_mean, const float* save_rstd, float* dy,
                        int64_t lddy, float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
                        hgv_stream_t stream);
+/* hgv_bn_act_bwd_pre without its statistics pass: when every consumer of the level was a projection that took it as
+ * (d, s, t), the incoming gradient is g = sum_p G_p W_p and the column sums of g and of g * d follow from the consumers'
+ * weight-gradient products raw_p = G_p^T d [n_p, H] and csum_p = column sums of G_p:
+ * sum_i g_ic = sum_p sum_n W_p[n,c] csum_p[n * cs_stride_p], sum_i g_ic d_ic = sum_p sum_n W_p[n,c] raw_p[n,c]. */
+int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* d, int64_t ldd, int64_t N,
+                           int H, int relu, float p, const float* gamma, const float* save_mean, const float* save_rstd,
+                           int nparts, const float* const* W, const int64_t* ldw, const float* const* raw, const int64_t* ldraw,
+                           const float* const* csum, const int64_t* cs_stride, const int* n, float* dy, int64_t lddy,
+                           float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* lddst, const float* const* raw, const int64_t* ldraw,
                      const int* N, const int* K, const float* const* s, const float* const* t, const float* const* colsum,
                      const int64_t* cs_stride, int accumulate, hgv_stream_t stream);

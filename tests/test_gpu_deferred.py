@@ -212,14 +212,28 @@ def test_train_step_with_deferred_levels_matches_the_plain_path(variant):
             _made.append(1)
             _orig(self, *a, **k)
         Fn.Deferred.__init__ = spy
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        Fn._lib.call = spy_call
         try:
             with use_noise(NoiseTape([t.clone() for t in tape])):
                 loss = loss_fn(model, xd, eid, bd, 1.0)
             loss.backward()
         finally:
             Fn.Deferred.__init__ = orig
+            Fn._lib.call = real_call
             Fn.set_deferred_levels(True)
         counts.append(len(made))
+        if deferred:
+            # levels whose consumers are all projections on (d, s, t) take their backward sums from those consumers'
+            # products; levels read another way (pooling reads the written-out matrix) from the matrices
+            assert "hgv_bn_act_bwd_pre_alg" in names, variant
+            if variant in ("pool", "custom_pool"):
+                assert "hgv_bn_act_bwd_pre" in names
         results.append((loss.detach().clone(), {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()},
                         {k: b.clone() for k, b in model.named_buffers()}))
     assert counts[0] > 0 and counts[1] == 0
