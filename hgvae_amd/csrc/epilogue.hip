@@ -35,6 +35,7 @@ struct EpArgs {
     const uint64_t* offset_dev;      // optional device word added to offset (advanced once per step under graph replay)
     int pre;                         // y already holds d = dropout(relu(y)) (written by the producing kernel; without a relu
                                      // a dropped element is -0.0f, a kept zero +0.0f): nothing is recomputed or regenerated
+    const float* y2;                 // pre, two noise sets: the activated matrix of the second set (same leading dimension as y)
 };
 
 template <bool VEC>
@@ -141,7 +142,8 @@ __device__ __forceinline__ float stored_d(const EpArgs& a, float d, float k) {
 }
 
 template <bool VEC, int NS, bool WD = false>
-__global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial, float* __restrict__ d_out = nullptr) {
+__global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial, float* __restrict__ d_out = nullptr,
+                                                  float* __restrict__ d_out2 = nullptr) {
     __shared__ float4 sh[512];
     __shared__ float4 sh2[512];
     const int t = threadIdx.x;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
                         if (h < nh) {
                             const float4 w = make_float4(stored_d(a, d[h].x, kk[h].x), stored_d(a, d[h].y, kk[h].y),
                                                          stored_d(a, d[h].z, kk[h].z), stored_d(a, d[h].w, kk[h].w));
-                            st4<VEC>(d_out, a.ldy, row, cc[h], a.H, w);
+                            st4<VEC>(set ? d_out2 : d_out, a.ldy, row, cc[h], a.H, w);
                         }
                     }
                 }
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
         }
         const double s1 = fin_tree(sh, sl, cl, a1);
         const double s2 = fin_tree(sh, sl, cl, a2);
-        if (sl == 0 && !ok && col_s && c < Hp) col_s[c] = col_t[c] = 0.f;       // pad columns stay zero
+        if (sl == 0 && !ok && col_s && c < Hp) col_s[set * Hp + c] = col_t[set * Hp + c] = 0.f;       // pad columns stay zero
         if (sl == 0 && ok) {
             const double mean = pivot + s1 / (double)N;
             double m2 = s2 - s1 * s1 / (double)N;
@@ -336,8 +338,8 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
             if (col_s) {
                 // the normalisation as one multiply-add per element: out = d * s + t with the rounded rstd the backward uses
                 const double sc = (double)(gamma ? gamma[c] : 1.f) * (double)save_rstd[set * H + c];
-                col_s[c] = (float)sc;
-                col_t[c] = (float)((double)(beta ? beta[c] : 0.f) - mean * (double)(float)sc);
+                col_s[set * Hp + c] = (float)sc;
+                col_t[set * Hp + c] = (float)((double)(beta ? beta[c] : 0.f) - mean * (double)(float)sc);
             }
             if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
             if (running_var) {
@@ -479,6 +481,9 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_stats(const EpArgs a, const B
             for (int set = 0; set < NS; ++set) {
                 float4 gv[2], d[2];
                 gv[0] = ldg4<VEC>(b, row, cc[0], a.H, set); gv[1] = ldg4<VEC>(b, row, cc[1], a.H, set);
+                if (NS == 2 && set == 1 && a.y2) {       // activated inputs: every set has a matrix of its own
+                    yv[0] = ld4<VEC>(a.y2, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y2, a.ldy, row, cc[1], a.H);
+                }
                 apply_d2(a, row, cp, yv, d, nullptr, set);
                 if (NS == 2) {
 #pragma unroll
@@ -620,6 +625,9 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_apply(const EpArgs a, const B
         for (int set = 0; set < NS; ++set) {
             float4 d[2], k[2], gv[2];
             gv[0] = ldg4<VEC>(b, row, cc[0], a.H, set); gv[1] = ldg4<VEC>(b, row, cc[1], a.H, set);
+            if (NS == 2 && set == 1 && a.y2) {           // activated inputs: every set has a matrix of its own
+                y[0] = ld4<VEC>(a.y2, a.ldy, row, cc[0], a.H); y[1] = ld4<VEC>(a.y2, a.ldy, row, cc[1], a.H);
+            }
             apply_d2(a, row, cp, y, d, k, set);
             if (NS == 2) {
 #pragma unroll
@@ -664,7 +672,7 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.thresh = (uint32_t)((double)p * 65536.0 + 0.5);
     a.mask = mask; a.seed = seed; a.offset = offset; a.offset2 = 0; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
-    a.pre = 0;
+    a.pre = 0; a.y2 = nullptr;
     // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread - two rows per
     // thread for small matrices, where the launch is as long as its longest workgroup (4 416 x 138: 4 % of a captured step
     // against 4 rows; one row per thread is slower again at width 256)
@@ -824,6 +832,8 @@ extern "C" int hgv_bn_act_bwd(const float* g, int64_t ldg, const float* g2, int6
     HGV_CHECK_LAUNCH("bn_act_bwd");
     return HGV_OK;
 }
+
+#define HGV_BN_PAIR_MAX_H 512      /* the two-draw backward kernels keep 4 * Hp column constants in an 8 KB LDS array */
 
 // ---- levels whose normalisation is left to their consumers ----------------------------------------------------------------
 // The pass that takes a level's column statistics can leave d = dropout(relu(y)) behind in place of y.  Then the
@@ -991,6 +1001,88 @@ extern "C" int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* 
     return HGV_OK;
 }
 
+// ---- the same for two dropout draws of one pre-activation (the two encode passes of a train step over the shared first
+// convolution, gvae/gvae_skipcon.py:166-171): y is overwritten with the first draw's d, d2 receives the second's; one read
+// of y.  save_mean / save_rstd hold [2][H], col_s / col_t [2][4 * ceil(H / 4)]; the running statistics take the first
+// draw's update, then the second's.  Philox noise only (p > 0), 16-byte rows.
+extern "C" int hgv_bn_stats_act2(float* y, float* d2, int64_t ldy, int64_t N, int H, int relu, float p, uint64_t seed,
+                                 uint64_t offset, uint64_t offset2, const uint64_t* offset_dev, const float* gamma,
+                                 const float* beta, float eps, float* running_mean, float* running_var, float momentum,
+                                 int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* col_s, float* col_t,
+                                 void* ws, size_t ws_bytes, hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, y, ldy, N, H, relu, p, nullptr, seed, offset, offset_dev, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(p > 0.f, HGV_EINVAL, "bn_stats_act2: two draws need p > 0");
+    HGV_REQUIRE(H <= HGV_BN_PAIR_MAX_H, HGV_EUNSUPPORTED, "bn_stats_act2: H=%d exceeds %d", H, HGV_BN_PAIR_MAX_H);
+    HGV_REQUIRE(d2 && save_mean && save_rstd && col_s && col_t && ws, HGV_EINVAL, "bn_stats_act2: null buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_stats_act2: workspace too small or misaligned");
+    const int Hp = a.CH * 4;
+    HGV_REQUIRE(vec4_ok(y, ldy, Hp) && vec4_ok(d2, ldy, Hp), HGV_EUNSUPPORTED, "bn_stats_act2: rows must be 16-byte aligned with padded leading dimensions");
+    a.offset2 = offset2;
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL((k_ep_stats<true, 2, true>), dim3(nb), dim3(256), 0, stream, a, partial, y, d2);
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 2,
+                       gamma, beta, col_s, col_t);
+    HGV_CHECK_LAUNCH("bn_stats_act2");
+    return HGV_OK;
+}
+
+// Backward of the two draws in one pass: g / g2 are the incoming gradients of the first draw's output (g2 nullable), h / h2
+// those of the second's, d1 / d2 the two activated matrices, dy the SUM of the two input gradients.  nparts0 + nparts1 parts
+// (hgv_bn_act_bwd_pre_alg; the first nparts0 belong to the first draw): with both counts > 0 the column sums come from the
+// consumers' products, with both 0 from a pass over the matrices.
+extern "C" int hgv_bn_act_bwd2_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* h, int64_t ldh,
+                                   const float* h2, int64_t ldh2, const float* d1, const float* d2, int64_t ldd, int64_t N,
+                                   int H, int relu, float p, const float* gamma, const float* save_mean,
+                                   const float* save_rstd, int nparts0, int nparts1, const float* const* W,
+                                   const int64_t* ldw, const float* const* raw, const int64_t* ldraw,
+                                   const float* const* csum, const int64_t* cs_stride, const int* n, float* dy, int64_t lddy,
+                                   float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes,
+                                   hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d1, ldd, N, H, relu, p, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(H <= HGV_BN_PAIR_MAX_H, HGV_EUNSUPPORTED, "bn_act_bwd2_pre: H=%d exceeds %d", H, HGV_BN_PAIR_MAX_H);
+    HGV_REQUIRE(g && ldg >= H && h && ldh >= H && d2 && dy && lddy >= H && save_mean && save_rstd && ws && (!g2 || ldg2 >= H) &&
+                (!h2 || ldh2 >= H), HGV_EINVAL, "bn_act_bwd2_pre: null/short buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_act_bwd2_pre: workspace too small or misaligned");
+    HGV_REQUIRE((nparts0 > 0) == (nparts1 > 0) && nparts0 >= 0 && nparts0 <= ALG_MAX_PARTS && nparts1 <= ALG_MAX_PARTS, HGV_EINVAL,
+                "bn_act_bwd2_pre: parts for both draws or for none (at most %d each)", ALG_MAX_PARTS);
+    a.pre = 1; a.mode = 0; a.y2 = d2;
+    const int Hp = a.CH * 4;
+    HGV_REQUIRE(vec4_ok(d1, ldd, Hp) && vec4_ok(d2, ldd, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(h, ldh, Hp) &&
+                vec4_ok(h2, ldh2, Hp) && vec4_ok(dy, lddy, Hp), HGV_EUNSUPPORTED,
+                "bn_act_bwd2_pre: rows must be 16-byte aligned with padded leading dimensions");
+    float* partial = (float*)ws;
+    float* sums = (float*)((char*)ws + hgv_align256(2048 * 2 * (size_t)Hp * sizeof(float)));
+    BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, h, ldh, h2, ldh2};
+    if (nparts0 > 0) {
+        HGV_REQUIRE(W && ldw && raw && ldraw && csum && cs_stride && n, HGV_EINVAL, "bn_act_bwd2_pre: null part arrays");
+        int first = 0;
+        for (int set = 0; set < 2; ++set) {
+            const int cnt = set ? nparts1 : nparts0;
+            AlgArgs q{};
+            q.nparts = cnt; q.H = H; q.Hp = Hp; q.mean = save_mean + set * H; q.rstd = save_rstd + set * H;
+            q.sums = sums + set * 2 * Hp; q.dgamma = dgamma; q.dbeta = dbeta; q.accumulate = (accumulate || set) ? 1 : 0;
+            for (int k = 0; k < cnt; ++k) {
+                const int j = first + k;
+                HGV_REQUIRE(W[j] && raw[j] && csum[j] && n[j] > 0 && ldw[j] >= H && ldraw[j] >= H, HGV_EINVAL, "bn_act_bwd2_pre: bad part %d", j);
+                q.part[k] = AlgPart{W[j], ldw[j], raw[j], ldraw[j], csum[j], cs_stride[j], n[j]};
+            }
+            hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+            first += cnt;
+        }
+    } else {
+        hipLaunchKernelGGL((k_ep_bwd_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, b, partial);
+        hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 2);
+    }
+    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb), dim3(256), (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
+    HGV_CHECK_LAUNCH("bn_act_bwd2_pre");
+    return HGV_OK;
+}
+
 // Weight-gradient finish for operands that were handed over un-normalised.  With x = a * s + t column by column,
 //   G^T x = (G^T a) diag(s) + colsum(G) t^T:
 // dst[n,k] (+)= raw[n,k] * s[k] + colsum[n * cs_stride] * t[k]   (s / t null: dst (+)= raw).  Up to three jobs per launch
@@ -1042,7 +1134,6 @@ extern "C" int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* ldd
 // of out (g2 nullable), h / h2 those of out2 (h2 nullable), dy the SUM of the two input gradients, dgamma / dbeta the
 // sums over both draws.  Results are those of the two separate calls bit for bit.  Philox noise with p > 0 only
 // (explicit masks: two calls); buffers 16-byte aligned with leading dimensions that are multiples of 4.
-#define HGV_BN_PAIR_MAX_H 512      /* the backward kernels keep 4 * Hp column constants in an 8 KB LDS array */
 extern "C" int hgv_bn_act_fwd2(const float* y, int64_t ldy, int64_t N, int H, int relu, float p, uint64_t seed,
                                uint64_t offset, uint64_t offset2, const uint64_t* offset_dev, const float* gamma,
                                const float* beta, float eps, float* running_mean, float* running_var, float momentum,

@@ -456,6 +456,131 @@ class _BnStats(torch.autograd.Function):
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 13
 
 
+_defer_pair = os.environ.get("HGVAE_DEFER_PAIR", "1") != "0"            # 0: the shared first level is written out (A/B)
+
+
+class _BnStatsPair(torch.autograd.Function):
+    """Two dropout draws of one pre-activation as two deferred levels, over one read of it: the buffer of ``y`` holds the
+    first draw's d afterwards, a new buffer the second's.  Returns two handles per draw and [2][s | t], mean [2, H],
+    rstd [2, H]; the backward pass handles both draws in one pass and returns the sum of the two input gradients."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, seed, offset, offset2, ctr, eps, momentum, tracked,
+                parts_a, parts_b):
+        n, h = y.shape
+        if n < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
+        hp = (h + 3) // 4 * 4
+        st = torch.empty(2, 2, hp, dtype=torch.float32, device=y.device)            # [s | t][draw][hp]
+        stats = torch.empty(2, 2, h, dtype=torch.float32, device=y.device)          # [mean | rstd][draw][h]
+        d1 = y.detach()
+        d2 = torch.empty_strided((n, h), (ld_of(y), 1), dtype=torch.float32, device=y.device)
+        _lib.call("hgv_bn_stats_act2", d1.data_ptr(), d2.data_ptr(), ld_of(d1), n, h, int(relu), float(p), seed, offset, offset2,
+                  ctr, _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
+                  float(momentum), _lib.ptr(tracked), stats[0].data_ptr(), stats[1].data_ptr(), st[0].data_ptr(),
+                  st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        ctx.cfg = (bool(relu), float(p))
+        ctx.parts = (parts_a, parts_b)
+        ctx.save_for_backward(d1, d2, gamma, stats, beta)
+        ctx.mark_non_differentiable(st, stats)
+        ctx.set_materialize_grads(False)
+        return y.view_as(y), y.view_as(y), d2, d2.view_as(d2), st, stats
+
+    @staticmethod
+    def backward(ctx, g, g2, h, h2, _st, _stats):
+        d1, d2, gamma, stats, beta = ctx.saved_tensors
+        relu, p = ctx.cfg
+        if g is None:
+            g, g2 = g2, None
+        if h is None:
+            h, h2 = h2, None
+        if g is None and h is None:
+            return (None,) * 16
+        n, hh = d1.shape
+        lib = _lib.load()
+        ws = _workspace(lib.hgv_bn_act_ws(n, hh), d1.device, "bn")
+        need = ctx.needs_input_grad
+        gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
+        direct = gbuf is not None and bbuf is not None
+        dgamma = gbuf if direct else torch.empty(hh, dtype=torch.float32, device=d1.device)
+        dbeta = bbuf if direct else torch.empty(hh, dtype=torch.float32, device=d1.device)
+        dy = new_padded(n, hh, d1.device, zero_pad=False)
+        grads = [as_padded(rowmajor(t)) if t is not None else None for t in (g, g2, h, h2)]
+        pa, pb = ctx.parts
+
+        def part_arrays(lists):
+            flat = [q for lst in lists for q in lst]
+            vp_t, i64_t, i32_t = _ctypes_arrays(max(len(flat), 1))
+            W, R, CS = vp_t(), vp_t(), vp_t()
+            ldw, ldr, css = i64_t(), i64_t(), i64_t()
+            nn_ = i32_t()
+            for q, (w, raw, cs) in enumerate(flat):
+                W[q], R[q], CS[q] = w.data_ptr(), raw.data_ptr(), cs.data_ptr()
+                ldw[q], ldr[q], css[q], nn_[q] = w.stride(0), raw.stride(0), (cs.stride(0) if cs.numel() > 1 else 1), w.size(0)
+            return W, ldw, R, ldr, CS, css, nn_
+
+        def usable(parts):
+            return _alg_sums and parts is not None and parts.complete() and all(w.size(1) == hh for (w, _, _) in parts.parts)
+
+        if grads[0] is None or grads[2] is None:
+            # only one of the two draws reached the loss: the single-draw backward on that draw
+            first = grads[0] is not None
+            a, a2 = (grads[0], grads[1]) if first else (grads[2], grads[3])
+            k, d, parts = (0, d1, pa) if first else (1, d2, pb)
+            if usable(parts):
+                W, ldw, R, ldr, CS, css, nn_ = part_arrays([parts.parts])
+                _lib.call("hgv_bn_act_bwd_pre_alg", a.data_ptr(), ld_of(a), _lib.ptr(a2), ld_of(a2) if a2 is not None else 0,
+                          d.data_ptr(), ld_of(d), n, hh, int(relu), float(p), _lib.ptr(gamma), stats[0, k].data_ptr(),
+                          stats[1, k].data_ptr(), len(parts.parts), W, ldw, R, ldr, CS, css, nn_, dy.data_ptr(), ld_of(dy),
+                          dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+            else:
+                _lib.call("hgv_bn_act_bwd_pre", a.data_ptr(), ld_of(a), _lib.ptr(a2), ld_of(a2) if a2 is not None else 0,
+                          d.data_ptr(), ld_of(d), n, hh, int(relu), float(p), _lib.ptr(gamma), stats[0, k].data_ptr(),
+                          stats[1, k].data_ptr(), dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(),
+                          1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        else:
+            a, a2, b, b2 = grads
+            alg = usable(pa) and usable(pb)
+            n0, n1 = (len(pa.parts), len(pb.parts)) if alg else (0, 0)
+            W, ldw, R, ldr, CS, css, nn_ = part_arrays([pa.parts, pb.parts] if alg else [])
+            _lib.call("hgv_bn_act_bwd2_pre", a.data_ptr(), ld_of(a), _lib.ptr(a2), ld_of(a2) if a2 is not None else 0,
+                      b.data_ptr(), ld_of(b), _lib.ptr(b2), ld_of(b2) if b2 is not None else 0, d1.data_ptr(), d2.data_ptr(),
+                      ld_of(d1), n, hh, int(relu), float(p), _lib.ptr(gamma), stats[0].data_ptr(), stats[1].data_ptr(), n0, n1,
+                      W, ldw, R, ldr, CS, css, nn_, dy.data_ptr(), ld_of(dy), dgamma.data_ptr(), dbeta.data_ptr(),
+                      1 if direct else 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        for parts in (pa, pb):
+            if parts is not None:
+                parts.parts.clear()
+        if direct:
+            dgamma = dbeta = None
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 13
+
+
+def bn_level_pair(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float):
+    """Training-mode relu? -> Dropout(p) -> BatchNorm1d for two successive dropout draws of the same fresh matrix ``y``
+    (the two encode passes of a train step over the shared first convolution), each result as a pair of handles for its
+    two consumers: ``((a, a'), (b, b'))`` - :class:`Deferred` levels inside :func:`deferred_levels`, else tensors
+    (:func:`bn_act_pair`) - or None when neither form applies (explicit noise tapes, p = 0, unaligned rows, no gradient)
+    and the caller makes two ordinary calls."""
+    if _defer and _defer_pair and torch.is_grad_enabled() and p >= DEFER_MIN_P and y.dim() == 2 \
+            and y.size(0) >= max(2, DEFER_MIN_ROWS) and y.requires_grad and y.grad_fn is not None and is_vec4(y) \
+            and y.size(1) <= 512 and noise_is_counter_based() and not on_branch_stream():
+        noise = current_noise()
+        _, seed, offset, ctr = noise.dropout(y.shape, y.device)
+        _, _, offset2, _ = noise.dropout(y.shape, y.device)
+        momentum = bn.momentum if bn.momentum is not None else 0.1
+        pa, pb = _GradParts(), _GradParts()
+        a, a2, b, b2, st, stats = _BnStatsPair.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, seed, offset,
+                                                     offset2, ctr, bn.eps, momentum, bn.num_batches_tracked, pa, pb)
+
+        def wrap(h, k, parts):
+            return Deferred(h, st[0, k], st[1, k], stats[0, k], stats[1, k], bn.weight, bn.bias, parts)
+        return (wrap(a, 0, pa), wrap(a2, 0, pa)), (wrap(b, 1, pb), wrap(b2, 1, pb))
+    return bn_act_pair(y, bn, relu, p)
+
+
 def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
     """One level: ``make_y()`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` builds the pre-activation (a fresh
     matrix that nothing else reads); the result is a tensor, or inside :func:`deferred_levels` a :class:`Deferred`

@@ -149,7 +149,7 @@ class SkipconVAE(_VAEBase):
             memo.clear()
             return kept if kind == "levels" else self._finish(kept, drop, bn, relu=True, fork=True)
         y = conv(x, g)
-        pair = Fn.bn_act_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
+        pair = Fn.bn_level_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
         if pair is not None:
             done = None
             if _two_streams(y.size(0)):  # the second pass may start here, next to the rest of the first

@@ -374,6 +374,21 @@ int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* g2, int64_t
                            int nparts, const float* const* W, const int64_t* ldw, const float* const* raw, const int64_t* ldraw,
                            const float* const* csum, const int64_t* cs_stride, const int* n, float* dy, int64_t lddy,
                            float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* The two-draw forms (the first level of the reference's two encode passes, gvae/gvae_skipcon.py:166-171, shares one
+ * pre-activation): hgv_bn_stats_act2 overwrites y with the first draw's d and writes the second draw's to d2 over one read
+ * of y (statistics [2][H], col_s / col_t [2][4 * ceil(H / 4)], running statistics updated for the first draw, then the
+ * second); hgv_bn_act_bwd2_pre is the backward of both in one pass (dy = sum of the two input gradients) with the column
+ * sums from the consumers' products (nparts0 / nparts1 > 0, parts as for hgv_bn_act_bwd_pre_alg) or from the matrices (0 / 0). */
+int hgv_bn_stats_act2(float* y, float* d2, int64_t ldy, int64_t N, int H, int relu, float p, uint64_t seed, uint64_t offset,
+                      uint64_t offset2, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
+                      float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
+                      float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
+int hgv_bn_act_bwd2_pre(const float* g, int64_t ldg, const float* g2, int64_t ldg2, const float* h, int64_t ldh, const float* h2,
+                        int64_t ldh2, const float* d1, const float* d2, int64_t ldd, int64_t N, int H, int relu, float p,
+                        const float* gamma, const float* save_mean, const float* save_rstd, int nparts0, int nparts1,
+                        const float* const* W, const int64_t* ldw, const float* const* raw, const int64_t* ldraw,
+                        const float* const* csum, const int64_t* cs_stride, const int* n, float* dy, int64_t lddy, float* dgamma,
+                        float* dbeta, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_wgrad_finish(int njobs, float* const* dst, const int64_t* lddst, const float* const* raw, const int64_t* ldraw,
                      const int* N, const int* K, const float* const* s, const float* const* t, const float* const* colsum,
                      const int64_t* cs_stride, int accumulate, hgv_stream_t stream);

@@ -130,6 +130,45 @@ def test_backward_of_a_deferred_level_equals_the_plain_level(relu):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,h", [(5000, 138), (70001, 138), (777, 64)])
+@pytest.mark.parametrize("which", ["both", "first", "second"])
+def test_two_draws_of_one_pre_activation_as_two_deferred_levels(n, h, which):
+    """hgv_bn_stats_act2 / hgv_bn_act_bwd2_pre: what hgv_bn_act_fwd2 / hgv_bn_act_bwd2 give on the same noise - outputs,
+    running buffers, input gradient and dgamma / dbeta bit for bit (the sums taken from the stored values, no consumers
+    registered) - also when only one of the two draws reaches the loss."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    gen = torch.Generator(device=dev()).manual_seed(n)
+    src = _rand((n, h), gen)
+    src[::7, ::3] = 0.0
+    gs = [_rand((n, h), gen) for _ in range(4)]
+    bn = _bn(h, gen)
+    bn2 = torch.nn.BatchNorm1d(h).to(dev()).train()
+    bn2.load_state_dict(bn.state_dict())
+    res = []
+    for deferred, norm in ((False, bn), (True, bn2)):
+        leaf = src.clone().requires_grad_(True)
+        y = _PaddedCopy.apply(leaf)
+        with use_noise(PhiloxNoise(1234)):
+            if deferred:
+                with Fn.deferred_levels():
+                    pair = Fn.bn_level_pair(y, norm, True, 0.5)
+                assert all(isinstance(t, Fn.Deferred) for draw in pair for t in draw)
+                outs = [t.tensor() for draw in pair for t in draw]
+            else:
+                pair = Fn.bn_act_pair(y, norm, True, 0.5)
+                outs = [t for draw in pair for t in draw]
+        sel = {"both": [0, 1, 2, 3], "first": [0, 1], "second": [3]}[which]
+        torch.autograd.backward([outs[i] for i in sel], [gs[i] for i in sel])
+        res.append(([o.detach().clone() for o in outs], leaf.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(bn.running_mean, bn2.running_mean) and torch.equal(bn.running_var, bn2.running_var)
+    assert int(bn2.num_batches_tracked) == 2
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
 def test_sage_convolution_on_a_deferred_operand(first, h_in):
     """SAGEConv over (d, s, t) = SAGEConv over the written-out d * s + t: forward, input gradient (with respect to `out`),
@@ -243,6 +282,59 @@ def test_train_step_with_deferred_levels_matches_the_plain_path(variant):
         if gb[k] is None:
             assert ga[k] is None or float(ga[k].abs().max()) == 0.0, k
             continue
+        scale = max(float(gb[k].abs().max()), 1e-30)
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale + 1e-7, (k, float((ga[k] - gb[k]).abs().max()), scale)
+    for k in bb:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("variant", ["skipcon", "attention"])
+def test_counter_noise_step_defers_the_shared_first_level_for_both_passes(variant):
+    """With counter-based noise the first encoder level serves both encode passes from one pass over the convolution
+    output (two dropout draws): deferred (hgv_bn_stats_act2 / hgv_bn_act_bwd2_pre, sums from the consumers' products)
+    against the written-out pair - same loss, gradients, BatchNorm buffers."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    from hgvae_amd import vae
+    gen = torch.Generator().manual_seed(5)
+    ei, n, batch = path_batch([120, 77, 300, 2, 45])
+    ei = torch.cat([ei, torch.randint(0, n, (2, 900), generator=gen)], 1)
+    f_in, h, z, ns = 12, 40, 6, 3
+    x = torch.randn(n, f_in, generator=gen)
+    torch.manual_seed(5)
+    cls = vae.SkipconVAE if variant == "skipcon" else vae.SkipconAttentionVAE
+    model = cls(f_in, h, z, ns).to(dev()).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    xd, eid, bd = x.to(dev()), ei.to(dev()), batch.to(dev())
+    results = []
+    for deferred in (True, False):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        Fn.set_deferred_levels(deferred)
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        Fn._lib.call = spy_call
+        try:
+            with use_noise(PhiloxNoise(99)):
+                loss = vae.train_step_loss(model, xd, eid, bd, 1.0)
+            loss.backward()
+        finally:
+            Fn._lib.call = real_call
+            Fn.set_deferred_levels(True)
+        if deferred:
+            assert "hgv_bn_stats_act2" in names and "hgv_bn_act_bwd2_pre" in names and "hgv_bn_act_fwd2" not in names
+        else:
+            assert "hgv_bn_act_fwd2" in names and "hgv_bn_stats_act2" not in names
+        results.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                        {k: b.clone() for k, b in model.named_buffers()}))
+    (la, ga, ba), (lb, gb, bb) = results
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    assert ga.keys() == gb.keys()
+    for k in gb:
         scale = max(float(gb[k].abs().max()), 1e-30)
         assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale + 1e-7, (k, float((ga[k] - gb[k]).abs().max()), scale)
     for k in bb:
