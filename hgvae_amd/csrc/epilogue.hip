@@ -9,8 +9,8 @@
 //
 // The activation is never materialised: the statistics pass and the normalise pass both
 // recompute d from the pre-activation y (3 N*H floats of traffic instead of 5).
-// Column statistics: each workgroup reduces a row range with sums shifted by the mean of the
-// range's first rows (no catastrophic cancellation), writes (mean_b, M2_b); a second tiny kernel
+// Column statistics: each workgroup reduces its rows (ep_block_rows) with sums shifted by the mean of its
+// first rows (no catastrophic cancellation), writes (mean_b, M2_b); a second tiny kernel
 // merges the partials with Chan's formula in fp64.  No atomics -> bitwise reproducible.
 //
 // Thread mapping: a thread owns the 4-column chunks cp and cp + CP of a row (CP = half the chunks, so
@@ -26,7 +26,7 @@ namespace {
 
 struct EpArgs {
     const float* y; int64_t ldy;
-    int64_t N; int H; int CH; int CP; int RPB; int64_t rows_per_block;   // CH chunks, CP chunk pairs per row
+    int64_t N; int H; int CH; int CP; int RPB;   // CH chunks, CP chunk pairs per row, RPB rows side by side per workgroup
     int relu; int mode;              // mode 0: no dropout, 1: explicit mask, 2: Philox
     float p; float scale; uint32_t thresh;   // Philox: keep iff 16 random bits >= thresh = round(p * 65536)
     const uint8_t* mask;             // [N, H] contiguous
@@ -132,6 +132,17 @@ __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, c
 
 constexpr int EP_PIVOT_ROWS = 8;
 
+// Rows of a workgroup: the groups of RPB consecutive rows number b, b + G, b + 2G, ... (G workgroups in the launch), so that at
+// any moment the launch as a whole works inside one window of G * RPB rows of every matrix it streams - neighbouring
+// workgroups share DRAM pages instead of each opening its own (worth 2 - 5 % per launch at 1.3 M rows against a contiguous
+// row range per workgroup).  The partial sums of a workgroup are over this fixed set, so results do not depend on scheduling.
+__host__ __device__ __forceinline__ int64_t ep_block_rows(int b, int G, int RPB, int64_t N) {
+    const int64_t NG = (N + RPB - 1) / RPB;                       // row groups in all; only the last one may be short
+    if (b >= NG) return 0;
+    const int64_t groups = (NG - 1 - b) / G + 1;
+    return groups * RPB - ((NG - 1) % G == b ? NG * RPB - N : 0);
+}
+
 // partial layout: [set][block][2][Hp] = (mean_b, M2_b), Hp = CH*4.  NS = 2: two noise sets (Philox offsets a.offset and
 // a.offset2) over one read of y - the statistics of two dropout draws of the same pre-activation.
 // WD: the activated values d are also written back over y (one set only): a dropped element as -0.0f when there is no relu
@@ -150,8 +161,7 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
     const bool active = t < a.RPB * a.CP;
     const int rsub = t / a.CP, cp = t - rsub * a.CP;
     const int nh = cp + a.CP < a.CH ? 2 : 1;
-    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t r1 = min(a.N, r0 + a.rows_per_block);
+    const int64_t r0 = (int64_t)blockIdx.x * a.RPB, r1 = a.N, rstep = (int64_t)gridDim.x * a.RPB;       // see ep_block_rows
     int cc[2];
     chunk_cols(a, cp, cc);
     // shift of the sums: the column mean over the block's first EP_PIVOT_ROWS rows.  A single row as the shift can sit
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
         }
     }
     if (active) {
-        for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
+        for (int64_t row = r0 + rsub; row < r1; row += rstep) {
             float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
 #pragma unroll
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
                     D2[h][0] += w.x; D2[h][1] += w.y; D2[h][2] += w.z; D2[h][3] += w.w;
                 }
             }
-            const double n = (double)(r1 - r0);
+            const double n = (double)ep_block_rows(blockIdx.x, gridDim.x, a.RPB, a.N);
             float* dst = partial + (int64_t)set * gridDim.x * 2 * Hp;
             for (int h = 0; h < nh; ++h) {
                 const float sv[4] = {s[set][h].x, s[set][h].y, s[set][h].z, s[set][h].w};
@@ -281,7 +291,7 @@ __device__ __forceinline__ double fin_tree(double (*sh)[17], int sl, int cl, dou
 // pivot p = mean of block 0 and d_b = mean_b - p,
 //   mean = p + sum(n_b d_b) / N,   M2 = sum(M2_b + n_b d_b^2) - (sum n_b d_b)^2 / N      (fp64).
 __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restrict__ partial, int nblocks,
-                                                           int64_t rows_per_block, int64_t N, int H, int Hp,
+                                                           int RPB, int64_t N, int H, int Hp,
                                                            float eps, float momentum,
                                                            float* __restrict__ running_mean,
                                                            float* __restrict__ running_var,
@@ -304,8 +314,6 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
         double a1 = 0.0, a2 = 0.0, pivot = 0.0;
         if (ok) {
             pivot = (double)part[c];
-            const double n_full = (double)rows_per_block;
-            const double n_tail = (double)(N - (int64_t)(nblocks - 1) * rows_per_block);
             // batches of 8 independent loads (clamped index, zero weight past the end) before the fp64 chain
             for (int b0 = sl; b0 < nblocks; b0 += 8 * FIN_SL) {
                 float m[8], q[8];
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(1024) void k_ep_stats_finalize(const float* __restr
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int b = b0 + u * FIN_SL;
-                    const double nb = b >= nblocks ? 0.0 : (b == nblocks - 1 ? n_tail : n_full);
+                    const double nb = b >= nblocks ? 0.0 : (double)ep_block_rows(b, nblocks, RPB, N);
                     const double d = (double)m[u] - pivot;
                     a1 += nb * d;
                     a2 += (b < nblocks ? (double)q[u] : 0.0) + nb * d * d;
@@ -371,8 +379,7 @@ __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs
     if (t >= a.RPB * a.CP) return;
     const int rsub = t / a.CP, cp = t - rsub * a.CP;
     const int nh = cp + a.CP < a.CH ? 2 : 1;
-    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t r1 = min(a.N, r0 + a.rows_per_block);
+    const int64_t r0 = (int64_t)blockIdx.x * a.RPB, r1 = a.N, rstep = (int64_t)gridDim.x * a.RPB;       // see ep_block_rows
     float4 mu[NS][2], rs[NS][2], ga[2], be[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(256) void k_ep_apply(const EpArgs a, const NormArgs
     }
     int cc[2];
     chunk_cols(a, cp, cc);
-    for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
+    for (int64_t row = r0 + rsub; row < r1; row += rstep) {
         float4 yv[2];
         yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
 #pragma unroll
@@ -445,8 +452,7 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_stats(const EpArgs a, const B
     const bool active = t < a.RPB * a.CP;
     const int rsub = t / a.CP, cp = t - rsub * a.CP;
     const int nh = cp + a.CP < a.CH ? 2 : 1;
-    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t r1 = min(a.N, r0 + a.rows_per_block);
+    const int64_t r0 = (int64_t)blockIdx.x * a.RPB, r1 = a.N, rstep = (int64_t)gridDim.x * a.RPB;       // see ep_block_rows
     float4 S1[NS][2], S2[NS][2];
 #pragma unroll
     for (int set = 0; set < NS; ++set) S1[set][0] = S1[set][1] = S2[set][0] = S2[set][1] = make_float4(0, 0, 0, 0);
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_stats(const EpArgs a, const B
         }
         int cc[2];
         chunk_cols(a, cp, cc);
-        for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
+        for (int64_t row = r0 + rsub; row < r1; row += rstep) {
             float4 yv[2];
             yv[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); yv[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
             int opaque = 0;
@@ -597,8 +603,7 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_apply(const EpArgs a, const B
     if (t >= a.RPB * a.CP) return;
     const int rsub = t / a.CP, cp = t - rsub * a.CP;
     const int nh = cp + a.CP < a.CH ? 2 : 1;
-    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t r1 = min(a.N, r0 + a.rows_per_block);
+    const int64_t r0 = (int64_t)blockIdx.x * a.RPB, r1 = a.N, rstep = (int64_t)gridDim.x * a.RPB;       // see ep_block_rows
     const float invn = 1.f / (float)a.N;
     float4 mu[NS][2], rs[NS][2], ga[2], sg[NS][2], sgx[NS][2];
 #pragma unroll
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_apply(const EpArgs a, const B
     }
     int cc[2];
     chunk_cols(a, cp, cc);
-    for (int64_t row = r0 + rsub; row < r1; row += a.RPB) {
+    for (int64_t row = r0 + rsub; row < r1; row += rstep) {
         float4 y[2], o[2];
         y[0] = ld4<VEC>(a.y, a.ldy, row, cc[0], a.H); y[1] = ld4<VEC>(a.y, a.ldy, row, cc[1], a.H);
         int opaque = 0;
@@ -673,14 +678,13 @@ int make_args(EpArgs& a, const float* y, int64_t ldy, int64_t N, int H, int relu
     a.mask = mask; a.seed = seed; a.offset = offset; a.offset2 = 0; a.offset_dev = offset_dev;
     a.mode = (p > 0.f) ? (mask ? 1 : 2) : 0;
     a.pre = 0; a.y2 = nullptr;
-    // row ranges: enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread - two rows per
-    // thread for small matrices, where the launch is as long as its longest workgroup (4 416 x 138: 4 % of a captured step
-    // against 4 rows; one row per thread is slower again at width 256)
+    // enough workgroups to fill the chip (8 per CU), at least 4 rows (of two chunks) per thread - two rows per thread for
+    // small matrices, where the launch is as long as its longest workgroup (4 416 x 138: 4 % of a captured step against
+    // 4 rows; one row per thread is slower again at width 256); which rows a workgroup takes: ep_block_rows
     int64_t nb = hgv_cdiv(N, (int64_t)a.RPB * (N >= 32768 ? 4 : 2));
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
-    a.rows_per_block = hgv_cdiv(N, nb);
-    *nblocks = (int)hgv_cdiv(N, a.rows_per_block);
+    *nblocks = (int)nb;
     return HGV_OK;
 }
 
@@ -705,7 +709,7 @@ int bn_act_fwd_launch(const EpArgs& a, int nb, const float* gamma, const float* 
     if (nsets == 2) hipLaunchKernelGGL((k_ep_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, partial);
     else if (vec) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
     else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((a.H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((a.H + 15) / 16), dim3(1024), 0, stream, partial, nb, a.RPB, a.N,
                        a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, nsets,
                        nullptr, nullptr, nullptr, nullptr);
     NormArgs n{save_mean, save_rstd, 0, eps, gamma, beta, out, ldo, out2};
@@ -860,7 +864,7 @@ extern "C" int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int rel
     float* partial = (float*)ws;
     if (vec4_ok(y, ldy, Hp)) hipLaunchKernelGGL((k_ep_stats<true, 1, true>), dim3(nb), dim3(256), 0, stream, a, partial, y);
     else hipLaunchKernelGGL((k_ep_stats<false, 1, true>), dim3(nb), dim3(256), 0, stream, a, partial, y);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.RPB, a.N,
                        a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 1,
                        gamma, beta, col_s, col_t);
     HGV_CHECK_LAUNCH("bn_stats_act");
@@ -1022,7 +1026,7 @@ extern "C" int hgv_bn_stats_act2(float* y, float* d2, int64_t ldy, int64_t N, in
     a.offset2 = offset2;
     float* partial = (float*)ws;
     hipLaunchKernelGGL((k_ep_stats<true, 2, true>), dim3(nb), dim3(256), 0, stream, a, partial, y, d2);
-    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.rows_per_block, a.N,
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.RPB, a.N,
                        a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 2,
                        gamma, beta, col_s, col_t);
     HGV_CHECK_LAUNCH("bn_stats_act2");
