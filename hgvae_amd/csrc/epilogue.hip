@@ -131,6 +131,7 @@ __device__ __forceinline__ void apply_d2(const EpArgs& a, int64_t row, int cp, c
 }
 
 constexpr int EP_PIVOT_ROWS = 8;
+constexpr int EP_WGS_TWO_SETS = 768;       // grid cap of the two-set backward pass: three workgroups per CU are resident
 
 // Rows of a workgroup: the groups of RPB consecutive rows number b, b + G, b + 2G, ... (G workgroups in the launch), so that at
 // any moment the launch as a whole works inside one window of G * RPB rows of every matrix it streams - neighbouring
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restr
             }
             const double n = (double)ep_block_rows(blockIdx.x, gridDim.x, a.RPB, a.N);
             float* dst = partial + (int64_t)set * gridDim.x * 2 * Hp;
-            for (int h = 0; h < nh; ++h) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) break;
                 const float sv[4] = {s[set][h].x, s[set][h].y, s[set][h].z, s[set][h].w};
                 float mv[4], qv[4];
 #pragma unroll
@@ -531,7 +534,9 @@ __global__ __launch_bounds__(256, 4) void k_ep_bwd_stats(const EpArgs a, const B
                 }
             }
             float* dst = partial + (int64_t)set * gridDim.x * 2 * Hp;
-            for (int h = 0; h < nh; ++h) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h >= nh) break;
                 const int c0 = (cp + h * a.CP) * 4;
                 *reinterpret_cast<float4*>(dst + ((int64_t)blockIdx.x * 2 + 0) * Hp + c0) =
                     make_float4((float)D1[h][0], (float)D1[h][1], (float)D1[h][2], (float)D1[h][3]);
@@ -585,10 +590,11 @@ __global__ __launch_bounds__(1024) void k_ep_bwd_finalize(const float* __restric
 }
 
 // NS = 2 keeps the per-column constants of both sets (mean, rstd, sum g, sum g*xhat) in LDS and fetches them inside
-// the row loop: as registers they push the kernel past 128 VGPRs, to three workgroups per CU and a second, third-full
-// round of the 1024 row ranges (launch with 2 * 4 * Hp floats of dynamic LDS; none for NS = 1).
+// the row loop (launch with 2 * 4 * Hp floats of dynamic LDS; none for NS = 1).  With up to seven matrices in flight per
+// row it still needs more than 128 VGPRs (forced into 128 it spilled 30 of them: 2.7 x its output in scratch writes), so it
+// runs three workgroups per CU, on a grid of EP_WGS_TWO_SETS so that one round holds every workgroup.
 template <bool VEC, int NS>
-__global__ __launch_bounds__(256, 4) void k_ep_bwd_apply(const EpArgs a, const BwdArgs b) {
+__global__ __launch_bounds__(256, NS == 2 ? 3 : 4) void k_ep_bwd_apply(const EpArgs a, const BwdArgs b) {
     extern __shared__ __attribute__((aligned(16))) float cst[];
     const int t = threadIdx.x;
     const int Hp = a.CH * 4;
@@ -1082,7 +1088,8 @@ extern "C" int hgv_bn_act_bwd2_pre(const float* g, int64_t ldg, const float* g2,
         hipLaunchKernelGGL((k_ep_bwd_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, b, partial);
         hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 2);
     }
-    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb), dim3(256), (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
+    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb < EP_WGS_TWO_SETS ? nb : EP_WGS_TWO_SETS), dim3(256),
+                       (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd2_pre");
     return HGV_OK;
 }
@@ -1178,7 +1185,8 @@ extern "C" int hgv_bn_act_bwd2(const float* g, int64_t ldg, const float* g2, int
     BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, h, ldh, h2, ldh2};
     hipLaunchKernelGGL((k_ep_bwd_stats<true, 2>), dim3(nb), dim3(256), 0, stream, a, b, partial);
     hipLaunchKernelGGL(k_ep_bwd_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, H, Hp, sums, dgamma, dbeta, accumulate, 2);
-    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb), dim3(256), (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
+    hipLaunchKernelGGL((k_ep_bwd_apply<true, 2>), dim3(nb < EP_WGS_TWO_SETS ? nb : EP_WGS_TWO_SETS), dim3(256),
+                       (size_t)2 * 4 * Hp * sizeof(float), stream, a, b);
     HGV_CHECK_LAUNCH("bn_act_bwd2");
     return HGV_OK;
 }
