@@ -154,7 +154,7 @@ __device__ __forceinline__ float stored_d(const EpArgs& a, float d, float k) {
 }
 
 template <bool VEC, int NS, bool WD = false>
-__global__ __launch_bounds__(256) void k_ep_stats(const EpArgs a, float* __restrict__ partial, float* __restrict__ d_out = nullptr,
+__global__ __launch_bounds__(256, (NS == 2 && WD) ? 4 : 1) void k_ep_stats(const EpArgs a, float* __restrict__ partial, float* __restrict__ d_out = nullptr,
                                                   float* __restrict__ d_out2 = nullptr) {
     __shared__ float4 sh[512];
     __shared__ float4 sh2[512];

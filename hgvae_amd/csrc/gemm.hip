@@ -427,6 +427,8 @@ struct TdArgs {
     int ngrp, kblk;             // groups of NB n blocks, k blocks
     float* partial;             // [sets][ngrp*kblk][NB*WN*WK][4][64]
     float* bias_partial;        // [sets][ngrp][NB*WN][16] or null
+    const float* G2; int64_t ldg2;   // optional second gradient matrix of the same width N (then no A2): the n blocks
+    int nblk1n;                      // [nblk1n, 2 nblk1n) take their columns from G2; 0 = one gradient matrix
 };
 
 // W floats from a 4-byte aligned address as one load.  The vector has exactly W live elements: a
@@ -460,13 +462,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
     // Per-lane byte offsets inside a 4-row step (constant for the whole kernel); the step's base
     // address is wave-uniform, so the per-step address arithmetic is scalar.
     uint32_t goff[NB];
+    const char* gbytes[NB];          // wave-uniform: which gradient matrix the n block reads, and its row pitch in bytes
+    int64_t gpitch[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int n0 = (zb * NB + b) * 16 * WN + WN * i;
-        goff[b] = (uint32_t)(((int64_t)kq * g.ldg + (n0 < g.N ? n0 : 0)) * 4);
+        const int nbi = zb * NB + b;
+        const bool g2 = g.nblk1n > 0 && nbi >= g.nblk1n;
+        const int n0 = (g2 ? nbi - g.nblk1n : nbi) * 16 * WN + WN * i;
+        const int64_t ld = g2 ? g.ldg2 : g.ldg;
+        goff[b] = (uint32_t)(((int64_t)kq * ld + (n0 < g.N ? n0 : 0)) * 4);
+        gbytes[b] = reinterpret_cast<const char*>(g2 ? g.G2 : g.G);
+        gpitch[b] = ld * 4;
     }
     const uint32_t aoff = (uint32_t)(((int64_t)kq * ldas + (k0 < Ks ? k0 : 0)) * 4);
-    const char* gbytes = reinterpret_cast<const char*>(g.G);
     const char* abytes = reinterpret_cast<const char*>(second ? g.A2 : g.A);
 
     f32x4 acc[TN_][WK];
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn_direct(const TdArgs g) {
         const int64_t r0 = min(lm, g.Mf - 4);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-            gr[d][b] = *reinterpret_cast<const typename TdVec<WN>::U*>(gbytes + r0 * g.ldg * 4 + goff[b]);
+            gr[d][b] = *reinterpret_cast<const typename TdVec<WN>::U*>(gbytes[b] + r0 * gpitch[b] + goff[b]);
         ar[d] = *reinterpret_cast<const typename TdVec<WK>::U*>(abytes + r0 * ldas * 4 + aoff);
         lm += 4;
     };
@@ -584,6 +592,8 @@ struct TrArgs {
     const float* a_last2; int64_t lda2; int K2; int kblk1;   // second source (k blocks >= kblk1) and its output matrix
     float* GW2; int64_t ldgw2;
     int accumulate;                                 // add to GW / gbias instead of overwriting them
+    const float* g_last2; int64_t ldg2; int nblk1n; // second gradient matrix (n blocks >= nblk1n): its last rows, its outputs
+    float* GWg2; int64_t ldgwg2; float* gbias2;
 };
 
 __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
@@ -616,10 +626,15 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
         if (is_bias) {
             const int zb = (int)(eb / (tn * 16)), rem = (int)(eb - (int64_t)zb * tn * 16);
             const int rr = rem >> 4, b = rr / g.wn, r = rr - b * g.wn;
-            const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (rem & 15) + r;
-            if (n < g.N) {
-                for (int q = 0; q < g.n_last; ++q) v += (double)g.g_last[q * g.ldg + n];
-                g.gbias[n] = g.accumulate ? g.gbias[n] + (float)v : (float)v;
+            const int nbi = zb * g.nb + b;
+            const bool g2 = g.nblk1n > 0 && nbi >= g.nblk1n;
+            const int n = (g2 ? nbi - g.nblk1n : nbi) * 16 * g.wn + g.wn * (rem & 15) + r;
+            if (n < g.N && !(g.nblk1n > 0 && nbi >= 2 * g.nblk1n)) {
+                const float* gl = g2 ? g.g_last2 : g.g_last;
+                const int64_t ldl = g2 ? g.ldg2 : g.ldg;
+                for (int q = 0; q < g.n_last; ++q) v += (double)gl[q * ldl + n];
+                float* dst = (g2 ? g.gbias2 : g.gbias) + n;
+                *dst = g.accumulate ? *dst + (float)v : (float)v;
             }
         } else {
             const int per_tile = tn * g.wk * 256;
@@ -628,14 +643,19 @@ __global__ __launch_bounds__(256) void k_reduce_tn(const TrArgs g) {
             const int rr = t / g.wk, c = t - rr * g.wk;
             const int b = rr / g.wn, r = rr - b * g.wn;
             const int zb = blk / g.kblk, yb = blk - zb * g.kblk;
-            const int n = (zb * g.nb + b) * 16 * g.wn + g.wn * (4 * (lane >> 4) + q) + r;
+            const int nbi = zb * g.nb + b;
+            const bool g2 = g.nblk1n > 0 && nbi >= g.nblk1n;
+            const int n = (g2 ? nbi - g.nblk1n : nbi) * 16 * g.wn + g.wn * (4 * (lane >> 4) + q) + r;
             const bool second = yb >= g.kblk1;
             const int k = (second ? yb - g.kblk1 : yb) * 16 * g.wk + g.wk * (lane & 15) + c;
-            if (n < g.N && k < (second ? g.K2 : g.K)) {
+            if (n < g.N && k < (second ? g.K2 : g.K) && !(g.nblk1n > 0 && nbi >= 2 * g.nblk1n)) {
                 const float* al = second ? g.a_last2 : g.a_last;
                 const int64_t ldl = second ? g.lda2 : g.lda;
-                for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)g.g_last[q2 * g.ldg + n] * (double)al[q2 * ldl + k];
-                float* dst = second ? g.GW2 + (int64_t)n * g.ldgw2 + k : g.GW + (int64_t)n * g.ldgw + k;
+                const float* gl = g2 ? g.g_last2 : g.g_last;
+                const int64_t ldgl = g2 ? g.ldg2 : g.ldg;
+                for (int q2 = 0; q2 < g.n_last; ++q2) v += (double)gl[q2 * ldgl + n] * (double)al[q2 * ldl + k];
+                float* dst = g2 ? g.GWg2 + (int64_t)n * g.ldgwg2 + k
+                                : (second ? g.GW2 + (int64_t)n * g.ldgw2 + k : g.GW + (int64_t)n * g.ldgw + k);
                 *dst = g.accumulate ? *dst + (float)v : (float)v;
             }
         }
@@ -720,10 +740,11 @@ struct TdPlan {
     int64_t tile_elems, bias_elems;  // floats per partial set
 };
 
-TdPlan td_plan(int64_t M, int N, int K, int K2 = 0) {
+// nsrc = 2: two gradient matrices of width N side by side (their n blocks follow one another)
+TdPlan td_plan(int64_t M, int N, int K, int K2 = 0, int nsrc = 1) {
     TdPlan p{};
     p.wn = td_width(N, 4);
-    const int nblk = (int)hgv_cdiv(N, 16 * p.wn);
+    const int nblk = nsrc * (int)hgv_cdiv(N, 16 * p.wn);
     p.nb = nblk < 3 ? nblk : 3;                               // n blocks per wave
     int wkmax = 27 / (p.nb * p.wn);
     if (wkmax > 4) wkmax = 4;
@@ -910,24 +931,29 @@ extern "C" int hgv_gemm_nt(const float* A1, int64_t lda1, int K1, const float* W
 
 namespace {
 
-size_t tn_ws_bytes(int64_t M, int N, int K1, int K2) {
+size_t tn_ws_bytes(int64_t M, int N, int K1, int K2, int nsrc = 1) {
     if (M <= 0 || N <= 0 || K1 <= 0) return 256;
-    const TdPlan p = td_plan(M, N, K1, K2);
+    const TdPlan p = td_plan(M, N, K1, K2, nsrc);
     const size_t sets = p.sets > 0 ? p.sets : 1;
     return hgv_align256(sets * p.tile_elems * 4) + hgv_align256(sets * p.bias_elems * 4);
 }
 
 int gemm_tn_impl(const float* G, int64_t ldg, int N, const float* A, int64_t lda, int K, float* GW, int64_t ldgw,
                  const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
-                 void* ws, size_t ws_bytes, hipStream_t stream) {
+                 void* ws, size_t ws_bytes, hipStream_t stream, const float* Gb = nullptr, int64_t ldgb = 0,
+                 float* GWb = nullptr, int64_t ldgwb = 0, float* gbias_b = nullptr) {
+    const int nsrc = Gb ? 2 : 1;
+    if (Gb) HGV_REQUIRE(!A2 && GWb && ldgb >= N && ldgwb >= K && ldgb < (1 << 27) && (gbias == nullptr) == (gbias_b == nullptr),
+                        HGV_EINVAL, "gemm_tn_gg: bad second gradient matrix");
     HGV_REQUIRE(M > 0 && N > 0 && K > 0, HGV_EINVAL, "gemm_tn: bad sizes");
     HGV_REQUIRE(G && A && GW && ws && ldg >= N && lda >= K && ldgw >= K, HGV_EINVAL, "gemm_tn: null buffer or leading dimension below the width");
     if (A2) HGV_REQUIRE(K2 > 0 && GW2 && lda2 >= K2 && ldgw2 >= K2 && lda2 < (1 << 27), HGV_EINVAL, "gemm_tn: bad second source");
     else K2 = 0;
     HGV_REQUIRE(N <= 288, HGV_EUNSUPPORTED, "gemm_tn: N=%d > 288", N);
     HGV_REQUIRE(ldg < (1 << 27) && lda < (1 << 27), HGV_EUNSUPPORTED, "gemm_tn: leading dimension too large");
-    HGV_REQUIRE(ws_bytes >= tn_ws_bytes(M, N, K, K2) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
-    const TdPlan p = td_plan(M, N, K, K2);
+    HGV_REQUIRE(ws_bytes >= tn_ws_bytes(M, N, K, K2, nsrc) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn: workspace too small or misaligned");
+    const TdPlan p = td_plan(M, N, K, K2, nsrc);
+    const int nblk1n = Gb ? (int)hgv_cdiv(N, 16 * p.wn) : 0;
     const size_t sets = p.sets > 0 ? p.sets : 1;
     float* partial = (float*)ws;
     float* bias_partial = (float*)((char*)ws + hgv_align256(sets * p.tile_elems * 4));
@@ -938,10 +964,12 @@ int gemm_tn_impl(const float* G, int64_t ldg, int N, const float* A, int64_t lda
         g.A2 = A2; g.lda2 = lda2; g.K2 = K2; g.kblk1 = p.kblk1;
         g.rows_per_slice = p.rows_per_slice; g.sets = p.sets; g.ngrp = p.ngrp; g.kblk = p.kblk;
         g.partial = partial; g.bias_partial = gbias ? bias_partial : nullptr;
+        g.G2 = Gb; g.ldg2 = ldgb; g.nblk1n = nblk1n;
         int rc = HGV_EUNSUPPORTED;
         bool hit = false;
 #define HGV_TD(a, b, c) if (!hit && p.wn == a && p.nb == b && p.wk == c) { hit = true; rc = launch_td<a, b, c>(g, p.spw, stream); }
         HGV_TD(1, 1, 1) HGV_TD(1, 1, 2) HGV_TD(1, 1, 3) HGV_TD(1, 1, 4)
+        HGV_TD(1, 2, 1) HGV_TD(1, 2, 2) HGV_TD(1, 2, 3) HGV_TD(1, 2, 4)      // two narrow gradient matrices side by side
         HGV_TD(2, 1, 1) HGV_TD(2, 1, 2) HGV_TD(2, 1, 3) HGV_TD(2, 1, 4)
         HGV_TD(2, 2, 1) HGV_TD(2, 2, 2) HGV_TD(2, 2, 3) HGV_TD(2, 2, 4)
         HGV_TD(2, 3, 1) HGV_TD(2, 3, 2) HGV_TD(2, 3, 3) HGV_TD(2, 3, 4)
@@ -961,6 +989,7 @@ int gemm_tn_impl(const float* G, int64_t ldg, int N, const float* A, int64_t lda
     r.g_last = G + Mf * ldg; r.a_last = A + Mf * lda; r.ldg = ldg; r.lda = lda; r.n_last = (int)(M - Mf);
     r.N = N; r.K = K; r.GW = GW; r.ldgw = ldgw; r.gbias = gbias; r.accumulate = accumulate;
     r.a_last2 = A2 ? A2 + Mf * lda2 : nullptr; r.lda2 = lda2; r.K2 = K2; r.kblk1 = p.kblk1; r.GW2 = GW2; r.ldgw2 = ldgw2;
+    r.g_last2 = Gb ? Gb + Mf * ldgb : nullptr; r.ldg2 = ldgb; r.nblk1n = nblk1n; r.GWg2 = GWb; r.ldgwg2 = ldgwb; r.gbias2 = gbias_b;
     const int64_t elems = p.tile_elems + (gbias ? p.bias_elems : 0);
     hipLaunchKernelGGL(k_reduce_tn, dim3((unsigned)hgv_cdiv(elems, 64)), dim3(256), 0, stream, r);
     HGV_CHECK_LAUNCH("gemm_tn");
@@ -971,6 +1000,7 @@ int gemm_tn_impl(const float* G, int64_t ldg, int N, const float* A, int64_t lda
 
 extern "C" size_t hgv_gemm_tn_ws(int64_t M, int N, int K) { return tn_ws_bytes(M, N, K, 0); }
 extern "C" size_t hgv_gemm_tn2_ws(int64_t M, int N, int K1, int K2) { return tn_ws_bytes(M, N, K1, K2); }
+extern "C" size_t hgv_gemm_tn_gg_ws(int64_t M, int N, int K) { return tn_ws_bytes(M, N, K, 0, 2); }
 
 // GW[N,K] (row-major, leading dimension ldgw >= K) (+)= G[M,N]^T A[M,K];  gbias[N] (+)= column sums of G (nullable).
 // accumulate != 0 adds to GW / gbias (gradient accumulation into an existing .grad buffer) instead of overwriting.
@@ -988,4 +1018,17 @@ extern "C" int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1,
                             int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     HGV_REQUIRE(A2 && GW2, HGV_EINVAL, "gemm_tn2: null second source");
     return gemm_tn_impl(G, ldg, N, A1, lda1, K1, GW1, ldgw1, A2, lda2, K2, GW2, ldgw2, M, gbias, accumulate, ws, ws_bytes, stream);
+}
+
+// Two weight gradients that share A in one pass: GWa[N,K] (+)= Ga^T A and GWb[N,K] (+)= Gb^T A for two gradient matrices
+// of the same width (a projection applied before the aggregation: W_l meets the transposed aggregate of the output
+// gradient, W_r the output gradient itself, both against the same input); gbias_a / gbias_b (+)= their column sums
+// (both or neither).
+extern "C" int hgv_gemm_tn_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda,
+                              int K, int64_t M, float* GWa, int64_t ldgwa, float* GWb, int64_t ldgwb, float* gbias_a,
+                              float* gbias_b, int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HGV_REQUIRE(Gb && GWb, HGV_EINVAL, "gemm_tn_gg: null second gradient matrix");
+    HGV_REQUIRE(2 * N <= 288, HGV_EUNSUPPORTED, "gemm_tn_gg: 2N=%d > 288", 2 * N);
+    return gemm_tn_impl(Ga, ldga, N, A, lda, K, GWa, ldgwa, nullptr, 0, 0, nullptr, 0, M, gbias_a, accumulate, ws, ws_bytes, stream,
+                        Gb, ldgb, GWb, ldgwb, gbias_b);
 }

@@ -1068,6 +1068,9 @@ def _gemm_tn(g, x, want_bias: bool, out: Optional[torch.Tensor] = None, bias_out
     return gw, gb
 
 
+_tn_gg = os.environ.get("HGVAE_TN_GG", "1") != "0"          # 0: two separate products (A/B measurements)
+
+
 def _check_gw(gw, n, k):
     if tuple(gw.shape) != (n, k) or gw.stride(1) != 1 or gw.stride(0) < k:
         raise _lib.HgvError(f"weight-gradient output of shape {tuple(gw.shape)} / strides {gw.stride()} for a {n}x{k} product")
@@ -1094,6 +1097,63 @@ def _gemm_tn2(g, xa, xb, want_bias: bool, out_a=None, out_b=None, bias_out=None,
     if ev:
         ev[1].record()
     return ga, gb_, gbias
+
+
+def _gemm_tn_gg(ga, gb, x, out_a=None, out_b=None, cs_a=None, cs_b=None, accumulate: bool = False):
+    """(ga^T @ x, gb^T @ x, column sums of ga, column sums of gb) in one pass over x for two gradient matrices of the same
+    width; see :func:`_gemm_tn`."""
+    m, n, k = ga.size(0), ga.size(1), x.size(1)
+    if gb.size(1) != n or gb.size(0) != m or x.size(0) != m:
+        raise _lib.HgvError(f"two-gradient product of {tuple(ga.shape)} and {tuple(gb.shape)} with {tuple(x.shape)}")
+    if accumulate and (out_a is None or out_b is None or cs_a is None or cs_b is None):
+        raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
+    wa = torch.empty(n, k, dtype=torch.float32, device=x.device) if out_a is None else out_a
+    wb = torch.empty(n, k, dtype=torch.float32, device=x.device) if out_b is None else out_b
+    _check_gw(wa, n, k)
+    _check_gw(wb, n, k)
+    ca = torch.empty(n, dtype=torch.float32, device=x.device) if cs_a is None else cs_a
+    cb = torch.empty(n, dtype=torch.float32, device=x.device) if cs_b is None else cs_b
+    ws = _workspace(_lib.load().hgv_gemm_tn_gg_ws(m, n, k), x.device, "gemm_tn")
+    ev = _probe.add("tn", (m, 2 * n, k)) if _probe is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("hgv_gemm_tn_gg", ga.data_ptr(), ld_of(ga), gb.data_ptr(), ld_of(gb), n, x.data_ptr(), ld_of(x), k, m, wa.data_ptr(),
+              wa.stride(0), wb.data_ptr(), wb.stride(0), ca.data_ptr(), cb.data_ptr(), 1 if accumulate else 0, ws.data_ptr(),
+              ws.numel(), _lib.stream())
+    if ev:
+        ev[1].record()
+    return wa, wb, ca, cb
+
+
+def _wgrad_gg(ga, gb, x, wa, wb, aff, bias, want_bias: bool):
+    """Weight gradients of  y = aggregate(x @ wa^T) + x @ wb^T + bias  from ga = the transposed aggregate of the output
+    gradient and gb = the output gradient: (gwa, gwb, gbias) for autograd, None where a gradient went straight into
+    ``.grad``.  ``aff`` as in :func:`_wgrad`."""
+    bufs = [_grad_buffer(wa), _grad_buffer(wb)]
+    bbuf = _grad_buffer(bias) if want_bias else None
+    direct = bufs[0] is not None and bufs[1] is not None and (not want_bias or bbuf is not None)
+    if aff is None:
+        if direct:
+            # the column sums of ga are not a gradient of anything: they land in a scratch vector
+            scratch = torch.zeros(ga.size(1), dtype=torch.float32, device=x.device)
+            cb = bbuf if want_bias else torch.zeros(ga.size(1), dtype=torch.float32, device=x.device)
+            _gemm_tn_gg(ga, gb, x, bufs[0], bufs[1], scratch, cb, accumulate=True)
+            return None, None, None
+        gwa, gwb, _, cb = _gemm_tn_gg(ga, gb, x)
+        return gwa, gwb, (cb if want_bias else None)
+    ra, rb, ca, cb = _gemm_tn_gg(ga, gb, x)
+    _contribute(aff, wa, ra, ca)
+    _contribute(aff, wb, rb, cb)
+    dsts = bufs if direct else [torch.empty_like(wa), torch.empty_like(wb)]
+    jobs = [(dsts[0], ra, aff, ca), (dsts[1], rb, aff, cb)]
+    gbias = None
+    if want_bias:
+        gbias = bbuf if direct else torch.empty_like(cb)
+        jobs.append((gbias.view(-1, 1), cb.view(-1, 1), None))
+    _wgrad_finish(jobs, cb, accumulate=direct)
+    if direct:
+        return None, None, None
+    return dsts[0], dsts[1], gbias
 
 
 def _weight_grad(g, x, w, bias=None, want_bias: bool = False):
@@ -1338,8 +1398,11 @@ class _SageConv(torch.autograd.Function):
             n_out, n_in = wl.shape
             gt = new_padded(n, n_out, g.device, zero_pad=False)      # gradient of the aggregated half
             _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
-            (gwl,), _ = _wgrad(gt, [(x, wl, ctx.aff, need[1])], None, False)
-            (gwr,), gb = _wgrad(g, [(x, wr, ctx.aff, need[3])], bl, want_bias)
+            if need[1] and need[3] and _tn_gg and 2 * n_out <= MAX_GEMM_N:
+                gwl, gwr, gb = _wgrad_gg(gt, g, x, wl, wr, ctx.aff, bl, want_bias)      # one pass over x for both
+            else:
+                (gwl,), _ = _wgrad(gt, [(x, wl, ctx.aff, need[1])], None, False)
+                (gwr,), gb = _wgrad(g, [(x, wr, ctx.aff, need[3])], bl, want_bias)
             if ctx.aff is not None and len(ctx.aff) > 2 and ctx.aff[2] is not None:
                 ctx.aff[2].uses += 1                      # one consumer, two parts (g_x = aggT(g) wl + g wr)
             if need[0]:

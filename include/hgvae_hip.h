@@ -299,6 +299,15 @@ int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1, int64_t ld
                  const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias, int accumulate,
                  void* ws, size_t ws_bytes, hgv_stream_t stream);
 
+/* Two weight gradients that share A in one pass: GWa[N,K] (+)= Ga^T A, GWb[N,K] (+)= Gb^T A for two gradient matrices of
+ * the same width N (2N <= 288), gbias_a / gbias_b (+)= their column sums (both or neither).  The backward pass of a
+ * SAGEConv whose projection runs before the aggregation (the mu / log-std convolutions, gvae/gvae_skipcon.py:113-118):
+ * W_l meets the transposed aggregate of the output gradient, W_r the output gradient itself, both against the layer input. */
+size_t hgv_gemm_tn_gg_ws(int64_t M, int N, int K);
+int hgv_gemm_tn_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda, int K,
+                   int64_t M, float* GWa, int64_t ldgwa, float* GWb, int64_t ldgwb, float* gbias_a, float* gbias_b,
+                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+
 /* ---- the same projections on the bf16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
  * hgv_gemm_nt16_supported: 1 when the split image of an N x (K1 + K2) weight, whole or in two parts along N,

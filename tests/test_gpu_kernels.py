@@ -649,6 +649,40 @@ def test_projection_kernels_at_benchmark_rows(shape, kind):
         Fn.set_projection(Fn.default_projection())
 
 
+@pytest.mark.parametrize("m,n,k", [(1283529, 56, 138), (5003, 56, 138), (4097, 28, 61), (3, 56, 138), (5, 7, 9), (801, 16, 40), (333, 1, 138), (70001, 64, 140),
+                                   (2049, 144, 33)])
+def test_two_gradient_matrices_against_one_operand(m, n, k):
+    """hgv_gemm_tn_gg: [Ga | Gb]^T A in one pass over A equals the two separate products (fp64 reference), with column
+    sums of both, overwriting and accumulating, outputs as row blocks of one matrix."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import new_padded
+    gen = torch.Generator(device=dev()).manual_seed(m + n + k)
+
+    def rnd(rows, cols):
+        t = new_padded(rows, cols, dev())
+        t.copy_(torch.randn(rows, cols, generator=gen, device=dev()))
+        return t
+
+    ga, gb, x = rnd(m, n), rnd(m, n), rnd(m, k)
+    both = torch.full((2 * n, k), 7.0, device=dev())
+    sums = torch.full((2, n), 7.0, device=dev())
+    Fn._gemm_tn_gg(ga, gb, x, both[:n], both[n:], sums[0], sums[1])
+    ref = torch.cat([ga, gb], 1).double().t() @ x.double()
+    refs = torch.stack([ga.double().sum(0), gb.double().sum(0)])
+    tol = 2e-6 * float(ref.abs().max()) + 1e-7 * m ** 0.5 * 4
+    tols = 2e-6 * float(refs.abs().max()) + 1e-7 * m ** 0.5 * 4
+    assert float((both.double() - ref).abs().max()) <= tol
+    assert float((sums.double() - refs).abs().max()) <= tols
+    Fn._gemm_tn_gg(ga, gb, x, both[:n], both[n:], sums[0], sums[1], accumulate=True)
+    assert float((both.double() - 2 * ref).abs().max()) <= 2 * tol
+    assert float((sums.double() - 2 * refs).abs().max()) <= 2 * tols
+    wa, wb, ca, cb = Fn._gemm_tn_gg(ga, gb, x)
+    sep_a, csa = Fn._gemm_tn(ga, x, True)
+    sep_b, csb = Fn._gemm_tn(gb, x, True)
+    for got, want in ((wa, sep_a), (wb, sep_b), (ca, csa), (cb, csb)):
+        assert float((got.double() - want.double()).abs().max()) <= tol
+
+
 def _scaled_cases():
     """Operands that exercise the power-of-two scales of the f16x3 kernels (name, rows, maker of A, maker of G)."""
     def randn(m, k, gen):
