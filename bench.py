@@ -214,15 +214,24 @@ def cpu_baseline(batch, kind, dims, sample_graphs, budget_s=10.0):
 
 def timed_steps(step, steps, warmup):
     """ms per step of ``step()`` on this GPU alone (no collective): warm-up, synchronise, time, synchronise."""
+    import gc
     import torch
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3 / steps
+    # the small workloads are bound by the host: a cycle collection inside the few timed steps would be most of a step
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3 / steps
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def secondary_workload(name, device, steps=5, warmup=2, captured=False):
@@ -251,6 +260,8 @@ def secondary_workload(name, device, steps=5, warmup=2, captured=False):
         opt.step()
         return loss
 
+    if batch.x.size(0) < 100_000:          # a few ms per step: more steps, so that one slow step is not a fifth of the figure
+        steps, warmup = 4 * steps, 2 * warmup
     ms = timed_steps(step, steps, warmup)
     n_graphs = batch.num_graphs
     out = {"name": name, "workload": WORKLOADS[name][0], "graphs": n_graphs, "nodes": batch.x.size(0),
@@ -259,7 +270,7 @@ def secondary_workload(name, device, steps=5, warmup=2, captured=False):
     if captured:
         from hgvae_amd.graphed import GraphedTrainStep
         g = GraphedTrainStep(model, opt, batch.x, batch.edge_index, batch.batch, 1.0, loss_fn=loss_fn, bucket=bucket, seed=1234)
-        ms_g = timed_steps(g, 4 * steps, warmup)
+        ms_g = timed_steps(g, 2 * steps, warmup)
         out["captured_ms_per_step"] = round(ms_g, 3)
         out["captured_value"] = round(n_graphs / (ms_g * 1e-3), 1)
         del g
