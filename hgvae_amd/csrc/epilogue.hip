@@ -877,6 +877,86 @@ extern "C" int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int rel
     return HGV_OK;
 }
 
+namespace {
+// Keep decisions of one dropout call as bits: bit c & 31 of bits[row * ldb + (c >> 5)] = 1 when element (row, c) is kept
+// (the decisions of keep8 with the same seed / offset; columns >= H read as kept).  The thread mapping is that of the
+// other kernels of this file (a thread owns the chunk pair cp, cp + CP of a row); the row's words are assembled in LDS.
+__global__ __launch_bounds__(256) void k_dropout_bits(const EpArgs a, uint32_t* __restrict__ bits, int64_t ldb, int W) {
+    __shared__ uint32_t sh[512];
+    const int t = threadIdx.x;
+    const bool active = t < a.RPB * a.CP;
+    const int rsub = t / a.CP, cp = t - rsub * a.CP;
+    for (int64_t r0 = (int64_t)blockIdx.x * a.RPB; r0 < a.N; r0 += (int64_t)gridDim.x * a.RPB) {
+        for (int e = t; e < a.RPB * W; e += 256) sh[e] = 0u;
+        __syncthreads();
+        const int64_t row = r0 + rsub;
+        if (active && row < a.N) {
+            float4 k[2];
+            keep8(a, row, cp, k);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c0 = (cp + h * a.CP) * 4;
+                if (h == 1 && cp + a.CP >= a.CH) break;
+                uint32_t nib = (k[h].x != 0.f ? 1u : 0u) | (k[h].y != 0.f ? 2u : 0u) | (k[h].z != 0.f ? 4u : 0u) | (k[h].w != 0.f ? 8u : 0u);
+                if (c0 + 1 >= a.H) nib |= 2u;
+                if (c0 + 2 >= a.H) nib |= 4u;
+                if (c0 + 3 >= a.H) nib |= 8u;
+                atomicOr(&sh[rsub * W + (c0 >> 5)], nib << (c0 & 31));      // distinct bits per thread: order is irrelevant
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < a.RPB * W; e += 256) {
+            const int64_t rr = r0 + e / W;
+            if (rr < a.N) bits[rr * ldb + (e % W)] = sh[e];
+        }
+        __syncthreads();
+    }
+}
+}  // namespace
+
+// Keep bits of one Philox dropout call over [N, H]: the decisions hgv_bn_stats_act / hgv_bn_act_fwd take for the same
+// (p, seed, offset, offset_dev).  bits: [N, ld_bits] 32-bit words, ld_bits >= ceil(4 * ceil(H / 4) / 32); bits of columns
+// in [H, 32 * ld_bits) covered by a chunk are set (kept).  For projections that store the activated level themselves.
+extern "C" int hgv_dropout_bits(int64_t N, int H, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                uint32_t* bits, int64_t ld_bits, hipStream_t stream) {
+    EpArgs a; int nb;
+    HGV_REQUIRE(bits != nullptr && p > 0.f, HGV_EINVAL, "dropout_bits: null buffer or p = 0");
+    int rc = make_args(a, reinterpret_cast<const float*>(bits), H, N, H, 0, p, nullptr, seed, offset, offset_dev, &nb);
+    if (rc != HGV_OK) return rc;
+    const int W = (a.CH * 4 + 31) / 32;
+    HGV_REQUIRE(ld_bits >= W, HGV_EINVAL, "dropout_bits: %lld words per row, %d needed", (long long)ld_bits, W);
+    HGV_REQUIRE(a.RPB * W <= 512, HGV_EUNSUPPORTED, "dropout_bits: H=%d too wide", H);
+    int64_t g = hgv_cdiv(N, a.RPB);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_dropout_bits, dim3((unsigned)g), dim3(256), 0, stream, a, bits, ld_bits, W);
+    HGV_CHECK_LAUNCH("dropout_bits");
+    return HGV_OK;
+}
+
+// The statistics half of hgv_bn_stats_act for a matrix that already holds d = dropout(relu(y)) (a projection stored it:
+// hgv_gemm_nt16h_act): one read of d, no write; same partial sums, hence the same mean / rstd / col_s / col_t / running
+// statistics bit for bit.
+extern "C" int hgv_bn_stats_pre(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
+                                float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                                float* save_mean, float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
+    EpArgs a; int nb;
+    int rc = make_args(a, d, ldd, N, H, 0, 0.f, nullptr, 0, 0, nullptr, &nb);
+    if (rc != HGV_OK) return rc;
+    HGV_REQUIRE(save_mean && save_rstd && col_s && col_t && ws, HGV_EINVAL, "bn_stats_pre: null buffer");
+    HGV_REQUIRE(ws_bytes >= hgv_bn_act_ws(N, H) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "bn_stats_pre: workspace too small or misaligned");
+    a.pre = 1;
+    const int Hp = a.CH * 4;
+    float* partial = (float*)ws;
+    if (vec4_ok(d, ldd, Hp)) hipLaunchKernelGGL((k_ep_stats<true, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    else hipLaunchKernelGGL((k_ep_stats<false, 1>), dim3(nb), dim3(256), 0, stream, a, partial);
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nb, a.RPB, a.N,
+                       a.H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 1,
+                       gamma, beta, col_s, col_t);
+    HGV_CHECK_LAUNCH("bn_stats_pre");
+    return HGV_OK;
+}
+
 // out = (d - mean) * rstd * gamma + beta for a consumer that needs the normalised matrix after all (same arithmetic as
 // the second pass of hgv_bn_act_fwd).
 extern "C" int hgv_bn_apply(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta,

@@ -177,6 +177,11 @@ struct NtHArgs {
     int paced;
     int pace_slot;                         // which copy of the progress counters a paced launch uses
     const int* gate; int gate_run_if;      // optional device word: the launch does its work only when (*gate != 0) == gate_run_if
+    // activated store (kernels instantiated with ACT): C <- dropout(relu(C)), the head of a level's relu -> Dropout ->
+    // BatchNorm1d tail (gvae/gvae_skipcon.py:105-107).  Keep decisions come as one bit per element (bit c & 31 of word
+    // c >> 5 of the row's act_ldb words; hgv_dropout_bits writes them).  A dropped element is stored as -0.0f when
+    // there is no relu in front and a kept zero as +0.0f, so later passes read relu and dropout off the stored values.
+    const uint32_t* act_bits; int64_t act_ldb; int act_relu; float act_scale;
 };
 
 // every thread of the launch reads the same word, written by an earlier kernel of the stream: a uniform early exit
@@ -225,7 +230,7 @@ __device__ __forceinline__ SplitH split8h(const f32x4 (&av)[2], float s) {
     return o;
 }
 
-template <int NT, int RING>
+template <int NT, int RING, bool ACT = false>
 __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
     const GeoH& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
@@ -409,6 +414,12 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                     // weights as the row operand: lane (i, kq) register r = C[row i][16 n + 4 kq + r]
                     const int64_t row = ctile * 16 + i;
                     if (row < a.M) {
+                        uint32_t keep_w[(NT + 1) / 2];        // ACT: the row's keep bits, 32 columns per word
+                        if (ACT) {
+                            const uint32_t* bp = a.act_bits + row * a.act_ldb;
+#pragma unroll
+                            for (int q = 0; q < (NT + 1) / 2; ++q) keep_w[q] = bp[q];
+                        }
 #pragma unroll
                         for (int n = 0; n < NT; ++n) {
                             const int col = (t0 + n) * 16 + 4 * kq;
@@ -418,6 +429,16 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                                 f32x4 o;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) o[r] = (acc[n][r] * inv_cur) * iw[r] + bs[r];
+                                if (ACT) {
+                                    const uint32_t nib = keep_w[n >> 1] >> (16 * (n & 1) + 4 * kq);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        float v = a.act_relu ? fmaxf(o[r], 0.f) : o[r];
+                                        v *= a.act_scale;
+                                        if (v == 0.f) v = 0.f;                       // a kept zero is +0
+                                        o[r] = ((nib >> r) & 1u) ? v : (a.act_relu ? 0.f : -0.f);
+                                    }
+                                }
                                 *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
                             }
                         }
@@ -442,11 +463,11 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     if (a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NT>
+template <int NT, bool ACT = false>
 __global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
-    nth_body<NT, nth_ring<NT>()>(a, lds_raw, part, blockIdx.x, gridDim.x);
+    nth_body<NT, nth_ring<NT>(), ACT>(a, lds_raw, part, blockIdx.x, gridDim.x);
 }
 
 template <int NT0, int NT1>
@@ -616,9 +637,9 @@ int raise_lds_h(Kern kern) {
 
 constexpr int nth_min_waves() { return 4; }
 
-template <int NT>
+template <int NT, bool ACT = false>
 int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
-    auto kern = k_gemm_nt16h<NT>;
+    auto kern = k_gemm_nt16h<NT, ACT>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
     const int cus = cu_count_h();
@@ -632,6 +653,7 @@ int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
 }
 
 int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t st) {
+    if (a.act_bits) return nt == 9 ? launch_nth<9, true>(a, part, lds, st) : HGV_EUNSUPPORTED;
     switch (nt) {
         case 1: return launch_nth<1>(a, part, lds, st);
         case 2: return launch_nth<2>(a, part, lds, st);
@@ -788,7 +810,8 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
-                          hipStream_t stream) {
+                          hipStream_t stream, const uint32_t* act_bits = nullptr, int64_t act_ldb = 0, int act_relu = 0,
+                          float act_scale = 1.f) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -802,6 +825,9 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     a.C = C; a.ldc = ldc; a.M = M; a.ntiles = hgv_cdiv(M, 16);
     a.gate = gate; a.gate_run_if = gate_run_if;
     a.pace_slot = hgv_pace_slot(stream);
+    a.act_bits = act_bits; a.act_ldb = act_ldb; a.act_relu = act_relu; a.act_scale = act_scale;
+    if (act_bits) HGV_REQUIRE(!a.g.stream && a.g.parts == 1 && a.g.tiles == 9 && act_ldb >= 5, HGV_EUNSUPPORTED,
+                              "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
     if (a.g.stream) {
         rc = launch_nths(a, stream);
@@ -823,6 +849,22 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
 extern "C" int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                               const float* bias, int64_t M, int N, float* C, int64_t ldc, hipStream_t stream) {
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream);
+}
+
+// 1 when hgv_gemm_nt16h_act can run this shape
+extern "C" int hgv_gemm_nt16h_act_supported(int N, int K1, int K2) {
+    GeoH g;
+    return (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && !g.stream && g.parts == 1 && g.tiles == 9) ? 1 : 0;
+}
+
+// hgv_gemm_nt16h that stores dropout(relu(C)) (relu optional): keep bit of element (row, c) = bit c & 31 of
+// keep_bits[row * ld_bits + (c >> 5)] (hgv_dropout_bits), kept values times scale = 1 / (1 - p).  A dropped element is
+// stored as -0.0f when relu == 0 (a kept zero as +0.0f), as hgv_bn_stats_act leaves them.
+extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                  const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits,
+                                  int64_t ld_bits, int relu, float scale, hipStream_t stream) {
+    HGV_REQUIRE(keep_bits != nullptr, HGV_EINVAL, "gemm_nt16h_act: null keep bits");
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, keep_bits, ld_bits, relu ? 1 : 0, scale);
 }
 
 // hgv_gemm_nt16h that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the

@@ -384,7 +384,7 @@ class _BnStats(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, mask, seed, offset, ctr, eps, momentum, tracked, fork,
-                parts=None):
+                parts=None, pre=False):
         ctx.parts = parts
         n, h = y.shape
         if n < 2:
@@ -396,10 +396,15 @@ class _BnStats(torch.autograd.Function):
         save_mean = torch.empty(h, dtype=torch.float32, device=y.device)
         save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
         d = y.detach()                 # same storage: overwritten behind autograd's back (y has no other reader)
-        _lib.call("hgv_bn_stats_act", d.data_ptr(), ld_of(d), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
-                  _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
-                  _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
-                  ws.data_ptr(), ws.numel(), _lib.stream())
+        if pre:                        # the producing projection stored d already: statistics only
+            _lib.call("hgv_bn_stats_pre", d.data_ptr(), ld_of(d), n, h, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+                      _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked), save_mean.data_ptr(),
+                      save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        else:
+            _lib.call("hgv_bn_stats_act", d.data_ptr(), ld_of(d), n, h, int(relu), float(p), _lib.ptr(mask), seed, offset, ctr,
+                      _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum),
+                      _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+                      ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (bool(relu), float(p))
         ctx.save_for_backward(d, gamma, save_mean, save_rstd, beta)
         ctx.mark_non_differentiable(st, save_mean, save_rstd)
@@ -416,7 +421,7 @@ class _BnStats(torch.autograd.Function):
         if g is None:
             g, g2 = g2, None
         if g is None:
-            return (None,) * 16
+            return (None,) * 17
         n, h = d.shape
         g = rowmajor(g)
         g2 = rowmajor(g2) if g2 is not None else None
@@ -453,7 +458,7 @@ class _BnStats(torch.autograd.Function):
             parts.parts.clear()
         if direct:
             dgamma = dbeta = None
-        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 13
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 14
 
 
 _defer_pair = os.environ.get("HGVAE_DEFER_PAIR", "1") != "0"            # 0: the shared first level is written out (A/B)
@@ -581,14 +586,26 @@ def bn_level_pair(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: floa
     return bn_act_pair(y, bn, relu, p)
 
 
-def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False):
+def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False, act_ok: bool = False):
     """One level: ``make_y()`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` builds the pre-activation (a fresh
     matrix that nothing else reads); the result is a tensor, or inside :func:`deferred_levels` a :class:`Deferred`
-    (a pair of either with ``fork``)."""
-    y = plain(make_y())
-    if _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P and y.dim() == 2 and y.size(0) >= max(2, DEFER_MIN_ROWS) \
-            and y.requires_grad and y.grad_fn is not None and is_vec4(y):
-        mask, seed, offset, ctr = current_noise().dropout(y.shape, y.device)
+    (a pair of either with ``fork``).  ``act_ok``: ``make_y`` is exactly one projection operator of this module (SAGEConv,
+    dual / concatenated linear) and nothing else, so its product may store relu -> dropout itself."""
+    global _act_request, _act_done
+    want = _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P
+    _act_done = None
+    _act_request = (relu, p) if (want and act_ok and _nt_act and noise_is_counter_based()) else None
+    try:
+        y = plain(make_y())
+    finally:
+        _act_request = None
+    done, _act_done = _act_done, None
+    pre = done is not None and done == (y.data_ptr(), y.size(0), y.size(1), relu, p)
+    if done is not None and not pre:
+        raise _lib.HgvError("a projection stored an activated level that is not this level's input")
+    if pre or (want and y.dim() == 2 and y.size(0) >= max(2, DEFER_MIN_ROWS) and y.requires_grad and y.grad_fn is not None
+               and is_vec4(y)):
+        mask, seed, offset, ctr = (None, 0, 0, None) if pre else current_noise().dropout(y.shape, y.device)
         momentum = bn.momentum if bn.momentum is not None else 0.1
         rm, rv, tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
         if on_branch_stream():         # see bn_act: the trunk may be updating the running statistics right now
@@ -597,7 +614,7 @@ def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: b
             rm, rv, tracked = stand_in[0], stand_in[1], None
         parts = _GradParts()
         outs = _BnStats.apply(y, bn.weight, bn.bias, rm, rv, relu, p, mask, seed, offset, ctr, bn.eps, momentum, tracked, fork,
-                              parts)
+                              parts, pre)
         st, mean, rstd = outs[-3], outs[-2], outs[-1]
         made = [Deferred(h, st[0], st[1], mean, rstd, bn.weight, bn.bias, parts) for h in outs[:-3]]
         return (made[0], made[1]) if fork else made[0]
@@ -894,14 +911,51 @@ def _assert_zero_pads(*operands) -> None:
             raise _lib.HgvError(f"projection operand of shape {tuple(t.shape)} (leading dimension {ld_of(t)}) has non-zero pad columns")
 
 
-def _gemm_nt(xa, img: _Image, xb, bias, n_out: int) -> torch.Tensor:
+# A level that wants its producing projection to store d = dropout(relu(y)) itself leaves (relu, p) here; the projection
+# that forms the level's pre-activation (``level_out``) takes it when its shape allows and reports in _act_done.
+_act_request = None
+_act_done = None
+_nt_act = os.environ.get("HGVAE_NT_ACT", "1") != "0"            # 0: the statistics pass applies relu / dropout (A/B)
+
+
+def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str):
+    """(relu, p, scale, bits, seed/offset record) for a projection that stores the activated level, or None."""
+    global _act_request
+    req, _act_request = _act_request, None
+    if req is None or kind != "f16x3" or m < max(2, DEFER_MIN_ROWS) or not _lib.load().hgv_gemm_nt16h_act_supported(n_out, k1, k2):
+        return None
+    relu, p = req
+    mask, seed, offset, ctr = current_noise().dropout((m, n_out), None)
+    if mask is not None:
+        raise _lib.HgvError("activated projection store: counter-based noise expected")
+    return relu, p, seed, offset, ctr
+
+
+def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
-    xa / xb must already be in the padded layout."""
+    xa / xb must already be in the padded layout.  ``level_out``: this product is the pre-activation a level asked for
+    (see ``_act_request``)."""
+    global _act_done
     m = xa.size(0)
     if _CHECK_PADS:
         _assert_zero_pads(xa, xb)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
+    act = _take_act(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0, img.kind) if (level_out and _act_request is not None) else None
+    if act is not None:
+        relu, p, seed, offset, ctr = act
+        words = (ld_of(out) + 31) // 32
+        bits = torch.empty((m, words), dtype=torch.int32, device=xa.device)
+        _lib.call("hgv_dropout_bits", m, n_out, float(p), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+        if ev:
+            ev[0].record()
+        _lib.call("hgv_gemm_nt16h_act", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
+                  xb.size(1) if xb is not None else 0, img.a.data_ptr(), _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out),
+                  bits.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)), _lib.stream())
+        if ev:
+            ev[1].record()
+        _act_done = (out.data_ptr(), m, n_out, relu, p)
+        return out
     if ev:
         ev[0].record()
     if img.kind == "auto":
@@ -1200,7 +1254,7 @@ class _DualLinear(torch.autograd.Function):
             fwd, bias_f = _image_affine(wa, aff_a, wb if xb is not None else None, aff_b, bias)
         else:
             bias_f = bias
-        y = _gemm_nt(xa, fwd, xb, bias_f, wa.size(0))
+        y = _gemm_nt(xa, fwd, xb, bias_f, wa.size(0), level_out=True)
         ctx.has_b, ctx.has_bias = xb is not None, bias is not None
         ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, wa, xb, wb, bias)
@@ -1249,7 +1303,7 @@ class _ConcatLinear(torch.autograd.Function):
             fwd, bias_f = _image_affine(wa, aff_a, wb, aff_b, bias)
         else:
             bias_f = bias
-        y = _gemm_nt(xa, fwd, xb, bias_f, w.size(0))
+        y = _gemm_nt(xa, fwd, xb, bias_f, w.size(0), level_out=True)
         ctx.has_bias = bias is not None
         ctx.aff_a, ctx.aff_b = aff_a, aff_b
         ctx.save_for_backward(xa, xb, w, bias)
@@ -1378,7 +1432,7 @@ class _SageConv(torch.autograd.Function):
                 fwd, bias_f = _image_affine(wl, aff, wr, aff, bl, ind_a=True)      # [wl diag(s) | wl t | wr diag(s)], bl + wr t
             elif aff is not None:
                 fwd, bias_f = _image_affine(wl, None, wr, aff, bl)         # [wl | wr diag(s)], bl + wr t
-            y = _gemm_nt(agg, fwd, x, bias_f, n_out)
+            y = _gemm_nt(agg, fwd, x, bias_f, n_out, level_out=True)
             ctx.save_for_backward(x, wl, wr, bl, agg)
         ctx.graph, ctx.mean, ctx.first, ctx.has_bias, ctx.aff = graph, mean, first, bl is not None, aff
         ctx.ind = (not first) and ind

@@ -306,7 +306,7 @@ int hgv_gemm_tn2(const float* G, int64_t ldg, int N, const float* A1, int64_t ld
 size_t hgv_gemm_tn_gg_ws(int64_t M, int N, int K);
 int hgv_gemm_tn_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda, int K,
                    int64_t M, float* GWa, int64_t ldgwa, float* GWb, int64_t ldgwb, float* gbias_a, float* gbias_b,
-                   int accumulate, void* ws, size_t ws_bytes, hipStream_t stream);
+                   int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
 /* ---- the same projections on the bf16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------
@@ -353,6 +353,18 @@ int hgv_gemm_nt16h(const float* A1, int64_t lda1, int K1, const float* A2, int64
  * (relu and dropout are read off the stored values). */
 int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int relu, float p, const uint8_t* mask, uint64_t seed,
                      uint64_t offset, const uint64_t* offset_dev, const float* gamma, const float* beta, float eps,
+                     float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
+                     float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
+
+/* Keep bits of one Philox dropout call over [N, H]: the decisions hgv_bn_stats_act / hgv_bn_act_fwd take for the same
+ * (p, seed, offset, offset_dev) - torch.nn.Dropout of the reference's level tails.  bits: [N, ld_bits] 32-bit words,
+ * ld_bits >= ceil(4 * ceil(H / 4) / 32); bit c & 31 of word c >> 5 = element (row, c) is kept. */
+int hgv_dropout_bits(int64_t N, int H, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, uint32_t* bits,
+                     int64_t ld_bits, hgv_stream_t stream);
+
+/* The statistics half of hgv_bn_stats_act for a matrix that already holds d = dropout(relu(y)) (hgv_gemm_nt16h_act stored
+ * it): one read, no write; mean / rstd / col_s / col_t / running statistics equal hgv_bn_stats_act's bit for bit. */
+int hgv_bn_stats_pre(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
                      float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
                      float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
 int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* cs1, const float* ct1,
@@ -413,6 +425,16 @@ int hgv_row_range_flag(const float* A1, int64_t lda1, int K1, const float* A2, i
 int hgv_gemm_nt16h_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                          const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
                          hgv_stream_t stream);
+
+/* hgv_gemm_nt16h that stores the head of a level's relu -> Dropout -> BatchNorm1d tail itself (gvae/gvae_skipcon.py:105-107):
+ * C <- dropout(relu(C)) (relu optional), keep bit of element (row, c) = bit c & 31 of keep_bits[row * ld_bits + (c >> 5)]
+ * (hgv_dropout_bits), kept values times scale = 1 / (1 - p); a dropped element is stored as -0.0f when relu == 0 and a
+ * kept zero as +0.0f, as hgv_bn_stats_act leaves them.  One-part images of 9 column tiles only (129..144 outputs:
+ * hgv_gemm_nt16h_act_supported); hgv_bn_stats_pre takes the statistics of the stored matrix. */
+int hgv_gemm_nt16h_act_supported(int N, int K1, int K2);
+int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                       const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits, int64_t ld_bits,
+                       int relu, float scale, hgv_stream_t stream);
 int hgv_gemm_nt16_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                         const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
                         hgv_stream_t stream);

@@ -169,6 +169,66 @@ def test_two_draws_of_one_pre_activation_as_two_deferred_levels(n, h, which):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("op,relu,n_out", [("sage", True, 138), ("concat", False, 138), ("dual", True, 144), ("dual", False, 129),
+                                           ("sage", True, 64), ("concat", True, 160)])
+def test_projection_stores_the_activated_level_itself(op, relu, n_out, monkeypatch):
+    """hgv_dropout_bits + hgv_gemm_nt16h_act + hgv_bn_stats_pre against the projection followed by hgv_bn_stats_act:
+    the stored d (signed zeros included), s / t, the running statistics and every gradient are the same bits; widths the
+    activated store does not cover take the other path by themselves."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import graph_of
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    n, k = 3001, 138
+    gen = torch.Generator(device=dev()).manual_seed(n_out + int(relu))
+    ei, nn_, _ = path_batch([n])
+    ei = torch.cat([ei, torch.randint(0, n, (2, 4000))], 1).to(dev())
+    graph = graph_of(ei, n)
+    xa0, xb0 = _rand((n, k), gen), _rand((n, k), gen)
+    w1, w2 = _rand((n_out, k), gen, 0.1), _rand((n_out, k), gen, 0.1)
+    bias = _rand((n_out,), gen, 0.1)
+    g1, g2 = _rand((n, n_out), gen), _rand((n, n_out), gen)
+    results = []
+    for act in (True, False):
+        monkeypatch.setattr(Fn, "_nt_act", act)
+        bn = _bn(n_out, torch.Generator(device=dev()).manual_seed(5))
+        xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+        wa, wb, b = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        if op == "sage":
+            make = lambda: Fn.sage_conv(xa, graph, wa, b, wb, mean=True)                  # noqa: E731
+        elif op == "concat":
+            wcat = torch.cat([wa, wb], 1)
+            make = lambda: Fn.concat_linear(xa, xb, wcat, b)                              # noqa: E731
+        else:
+            make = lambda: Fn.dual_linear(xa, wa, xb, wb, b)                              # noqa: E731
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        monkeypatch.setattr(Fn._lib, "call", spy_call)
+        with use_noise(PhiloxNoise(4321)), Fn.deferred_levels():
+            lvl_a, lvl_b = Fn.bn_level(make, bn, relu, 0.5, True, fork=True, act_ok=True)
+        monkeypatch.setattr(Fn._lib, "call", real_call)
+        covered = bool(Fn._lib.load().hgv_gemm_nt16h_act_supported(n_out, k, 0 if op == "none" else k))
+        assert covered == (n_out in (138, 129)), (n_out, covered)      # one-part images of nine column tiles
+        assert ("hgv_gemm_nt16h_act" in names) == (act and covered)
+        assert ("hgv_bn_stats_pre" in names) == (act and covered)
+        assert isinstance(lvl_a, Fn.Deferred)
+        d = lvl_a.d.detach().clone()
+        torch.autograd.backward([lvl_a.tensor(), lvl_b.tensor()], [g1, g2])
+        grads = [t.grad.clone() for t in (xa, wa, wb, b) if t.grad is not None] + ([xb.grad.clone()] if xb.grad is not None else [])
+        results.append((d, lvl_a.s.clone(), lvl_a.t.clone(), bn.running_mean.clone(), bn.running_var.clone(),
+                        bn.weight.grad.clone(), bn.bias.grad.clone(), grads))
+    a, b_ = results
+    assert torch.equal(a[0].view(torch.int32), b_[0].view(torch.int32))          # the same bits, signed zeros included
+    for u, v in zip(a[1:7], b_[1:7]):
+        assert torch.equal(u, v)
+    assert len(a[7]) == len(b_[7])
+    for u, v in zip(a[7], b_[7]):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
 def test_sage_convolution_on_a_deferred_operand(first, h_in):
     """SAGEConv over (d, s, t) = SAGEConv over the written-out d * s + t: forward, input gradient (with respect to `out`),
