@@ -957,6 +957,23 @@ extern "C" int hgv_bn_stats_pre(const float* d, int64_t ldd, int64_t N, int H, c
     return HGV_OK;
 }
 
+// The merge step of the level statistics on its own, for partial statistics another kernel left (hgv_gemm_nt16h_act_stats):
+// partial[nparts][2][Hp] = (mean, M2) of part p over the rows of the group_rows-row groups p, p + nparts, ... of [0, N).
+// Writes what hgv_bn_stats_act writes (mean / rstd, col_s / col_t, running statistics).
+extern "C" int hgv_bn_stats_merge(const float* partial, int nparts, int group_rows, int64_t N, int H, const float* gamma,
+                                  const float* beta, float eps, float* running_mean, float* running_var, float momentum,
+                                  int64_t* num_batches_tracked, float* save_mean, float* save_rstd, float* col_s, float* col_t,
+                                  hipStream_t stream) {
+    HGV_REQUIRE(partial && nparts > 0 && group_rows > 0 && N > 1 && H > 0 && H <= 2048, HGV_EINVAL, "bn_stats_merge: bad arguments");
+    HGV_REQUIRE(save_mean && save_rstd && col_s && col_t, HGV_EINVAL, "bn_stats_merge: null buffer");
+    const int Hp = (H + 3) / 4 * 4;
+    hipLaunchKernelGGL(k_ep_stats_finalize, dim3((Hp + 15) / 16), dim3(1024), 0, stream, partial, nparts, group_rows, N,
+                       H, Hp, eps, momentum, running_mean, running_var, save_mean, save_rstd, num_batches_tracked, 1,
+                       gamma, beta, col_s, col_t);
+    HGV_CHECK_LAUNCH("bn_stats_merge");
+    return HGV_OK;
+}
+
 // out = (d - mean) * rstd * gamma + beta for a consumer that needs the normalised matrix after all (same arithmetic as
 // the second pass of hgv_bn_act_fwd).
 extern "C" int hgv_bn_apply(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta,

@@ -182,7 +182,35 @@ struct NtHArgs {
     // c >> 5 of the row's act_ldb words; hgv_dropout_bits writes them).  A dropped element is stored as -0.0f when
     // there is no relu in front and a kept zero as +0.0f, so later passes read relu and dropout off the stored values.
     const uint32_t* act_bits; int64_t act_ldb; int act_relu; float act_scale;
+    // ... and its column statistics (kernels instantiated with ACT = 2): every wave leaves (mean, M2) of the rows it
+    // stored in stat_partial[wave][2][stat_hp] - wave w of W owns the 16-row tiles w, w + W, ... - for the merge that
+    // the statistics kernels of the level tail use.  The sums are plain sums of d and d^2 over the few hundred rows of a
+    // wave, M2 = S2 - S1^2 / n formed in fp64: behind a dropout of rate p the stored values satisfy mean^2 / variance <=
+    // (1 - p) / p (the zeros it inserts are part of the variance), so nothing cancels as long as p is not small -
+    // callers use this form from p = 0.2 upwards
+    float* stat_partial; int stat_hp;
 };
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// One step of the reduce-scatter over the 16 lanes that hold the rows of a tile: a lane keeps the half of its values
+// that its bit selects (second half when set) and adds the partner's values of the same half; the partner (CTRL) has the
+// opposite bit.  x1 / x2: sums and sums of squares, NIN values in, first half NH = ceil(NIN / 2) (the second half is
+// padded with zeros).  FIRST: x2 is formed here as the square of x1.
+template <int CTRL, int NIN, bool FIRST>
+__device__ __forceinline__ void rs_step(float (&x1)[36], float (&x2)[36], bool bit) {
+    constexpr int NH = (NIN + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        const float a1 = x1[j], b1 = (NH + j < NIN) ? x1[NH + j] : 0.f;
+        const float a2 = FIRST ? a1 * a1 : x2[j], b2 = FIRST ? b1 * b1 : ((NH + j < NIN) ? x2[NH + j] : 0.f);
+        const float keep1 = bit ? b1 : a1, send1 = bit ? a1 : b1;
+        const float keep2 = bit ? b2 : a2, send2 = bit ? a2 : b2;
+        x1[j] = keep1 + dpp_mov<CTRL>(send1);
+        x2[j] = keep2 + dpp_mov<CTRL>(send2);
+    }
+}
 
 // every thread of the launch reads the same word, written by an earlier kernel of the stream: a uniform early exit
 #define HGV_GATE_EXIT(a) if ((a).gate != nullptr && ((*(a).gate != 0) ? 1 : 0) != (a).gate_run_if) return
@@ -230,7 +258,7 @@ __device__ __forceinline__ SplitH split8h(const f32x4 (&av)[2], float s) {
     return o;
 }
 
-template <int NT, int RING, bool ACT = false>
+template <int NT, int RING, int ACT = 0>
 __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
     const GeoH& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
@@ -241,6 +269,7 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     int4* tab = reinterpret_cast<int4*>(lds_raw + img);
     float* bias_s = reinterpret_cast<float*>(lds_raw + img + (size_t)g.chunks * 64);
     float* invw_s = bias_s + NT * 16;
+    float st1[3] = {0.f, 0.f, 0.f}, st2[3] = {0.f, 0.f, 0.f};      // ACT = 2: this lane's share of the wave's column sums
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)part * img);
         f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
@@ -288,7 +317,7 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     int* pace_base = pace_ctr_h + a.pace_slot * (2 * PACE_WGS * PACE_WAVES);
     int* pace_mine = pace_base + ((part * PACE_WGS + wg_rank) * PACE_WAVES + wib);
     const int* pace_twin = pace_base + (((part ^ 1) * PACE_WGS + wg_rank) * PACE_WAVES + wib);
-    bool pace = a.paced != 0;
+    bool pace = ACT == 0 && a.paced != 0;          // the activated stores are one-part launches: never paced
     int pace_step = 0;
     int pace_seen[RING];
 #pragma unroll
@@ -413,6 +442,11 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                 if (fresh) {
                     // weights as the row operand: lane (i, kq) register r = C[row i][16 n + 4 kq + r]
                     const int64_t row = ctile * 16 + i;
+                    float u1[36], u2[36];                     // ACT = 2: the stored values (0 for rows past M)
+                    if (ACT == 2) {
+#pragma unroll
+                        for (int q = 0; q < 36; ++q) u1[q] = 0.f;
+                    }
                     if (row < a.M) {
                         uint32_t keep_w[(NT + 1) / 2];        // ACT: the row's keep bits, 32 columns per word
                         if (ACT) {
@@ -440,8 +474,21 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
                                     }
                                 }
                                 *reinterpret_cast<f32x4*>(a.C + row * a.ldc + col) = o;
+                                if (ACT == 2 && NT == 9) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) u1[4 * n + r] = o[r];
+                                }
                             }
                         }
+                    }
+                    if (ACT == 2 && NT == 9) {
+                        // column sums over the tile's 16 rows: four reduce-scatter steps (i ^ 8, mirror inside 8, i ^ 2, i ^ 1)
+                        rs_step<0x128, 36, true>(u1, u2, (i & 8) != 0);       // row_ror:8
+                        rs_step<0x141, 18, false>(u1, u2, (i & 4) != 0);      // row_half_mirror
+                        rs_step<0x4E, 9, false>(u1, u2, (i & 2) != 0);        // quad_perm [2,3,0,1]
+                        rs_step<0xB1, 5, false>(u1, u2, (i & 1) != 0);        // quad_perm [1,0,3,2]
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { st1[q] += u1[q]; st2[q] += u2[q]; }
                     }
                     cq = 0; ctile += nw;
 #pragma unroll
@@ -460,10 +507,36 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
             }
         }
     }
-    if (a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ACT == 0 && a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ACT == 2 && NT == 9) {
+        // which of the 36 values (v = 4 n + r: column 16 n + 4 kq + r) the lane's three sums belong to: the halves kept above
+        const int b3 = (i >> 3) & 1, b2 = (i >> 2) & 1, b1 = (i >> 1) & 1, b0 = i & 1;
+        const int len_c = b1 ? 4 : 5;
+        const int base = 18 * b3 + 9 * b2 + 5 * b1 + 3 * b0;
+        const int len = b0 ? len_c - 3 : 3;
+        // rows of this wave: tiles gw, gw + nw, ...; only the last tile of the matrix may be short
+        const int64_t last = a.ntiles - 1;
+        const double nrows = (double)(my_tiles * 16 - ((my_tiles > 0 && last % nw == gw) ? a.ntiles * 16 - a.M : 0));
+        float* dst = a.stat_partial + gw * 2 * a.stat_hp;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int v = base + q;
+            const int col = 16 * (v >> 2) + 4 * kq + (v & 3);
+            if (q < len && col < a.stat_hp) {
+                float mean = 0.f, m2 = 0.f;
+                if (my_tiles > 0) {
+                    const double s1 = (double)st1[q], s2 = (double)st2[q];
+                    mean = (float)(s1 / nrows);
+                    m2 = (float)(s2 - s1 * s1 / nrows);
+                }
+                dst[col] = mean;
+                dst[a.stat_hp + col] = m2;
+            }
+        }
+    }
 }
 
-template <int NT, bool ACT = false>
+template <int NT, int ACT = 0>
 __global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
@@ -637,23 +710,32 @@ int raise_lds_h(Kern kern) {
 
 constexpr int nth_min_waves() { return 4; }
 
-template <int NT, bool ACT = false>
+// workgroups and waves per workgroup of a one-part launch over ntiles row tiles
+template <int NT>
+void nth_grid(int64_t ntiles, int64_t* wpb_out, int64_t* blocks_out) {
+    const int cus = cu_count_h();
+    int64_t wpb = hgv_cdiv(ntiles, cus);
+    if (wpb < nth_min_waves()) wpb = nth_min_waves();
+    if (wpb > nth_waves<NT>()) wpb = nth_waves<NT>();
+    int64_t blocks = hgv_cdiv(ntiles, wpb);
+    if (blocks > cus) blocks = cus;
+    *wpb_out = wpb; *blocks_out = blocks;
+}
+
+template <int NT, int ACT = 0>
 int launch_nth(const NtHArgs& a, int part, size_t lds, hipStream_t st) {
     auto kern = k_gemm_nt16h<NT, ACT>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
-    const int cus = cu_count_h();
-    int64_t wpb = hgv_cdiv(a.ntiles, cus);
-    if (wpb < nth_min_waves()) wpb = nth_min_waves();
-    if (wpb > nth_waves<NT>()) wpb = nth_waves<NT>();
-    int64_t blocks = hgv_cdiv(a.ntiles, wpb);
-    if (blocks > cus) blocks = cus;
+    int64_t wpb, blocks;
+    nth_grid<NT>(a.ntiles, &wpb, &blocks);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3((unsigned)(64 * wpb)), lds, st, a, part);
     return HGV_OK;
 }
 
 int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t st) {
-    if (a.act_bits) return nt == 9 ? launch_nth<9, true>(a, part, lds, st) : HGV_EUNSUPPORTED;
+    if (a.act_bits && a.stat_partial) return nt == 9 ? launch_nth<9, 2>(a, part, lds, st) : HGV_EUNSUPPORTED;
+    if (a.act_bits) return nt == 9 ? launch_nth<9, 1>(a, part, lds, st) : HGV_EUNSUPPORTED;
     switch (nt) {
         case 1: return launch_nth<1>(a, part, lds, st);
         case 2: return launch_nth<2>(a, part, lds, st);
@@ -811,7 +893,7 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
                           hipStream_t stream, const uint32_t* act_bits = nullptr, int64_t act_ldb = 0, int act_relu = 0,
-                          float act_scale = 1.f) {
+                          float act_scale = 1.f, float* stat_partial = nullptr) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -826,6 +908,7 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     a.gate = gate; a.gate_run_if = gate_run_if;
     a.pace_slot = hgv_pace_slot(stream);
     a.act_bits = act_bits; a.act_ldb = act_ldb; a.act_relu = act_relu; a.act_scale = act_scale;
+    a.stat_partial = stat_partial; a.stat_hp = (N + 3) / 4 * 4;
     if (act_bits) HGV_REQUIRE(!a.g.stream && a.g.parts == 1 && a.g.tiles == 9 && act_ldb >= 5, HGV_EUNSUPPORTED,
                               "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
@@ -865,6 +948,25 @@ extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const f
                                   int64_t ld_bits, int relu, float scale, hipStream_t stream) {
     HGV_REQUIRE(keep_bits != nullptr, HGV_EINVAL, "gemm_nt16h_act: null keep bits");
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, keep_bits, ld_bits, relu ? 1 : 0, scale);
+}
+
+// hgv_gemm_nt16h_act that also leaves the column statistics of what it stored: stat_partial[parts][2][Hp] (Hp = 4 *
+// ceil(N / 4)) receives per part p of hgv_gemm_nt16h_act_parts(M) the (mean, M2) of the rows of the 16-row groups p,
+// p + parts, p + 2 parts, ... - the layout hgv_bn_stats_merge finishes.  Plain fp32 sums of d and d^2 per part: meant for
+// levels behind a dropout of rate >= 0.2, whose zeros bound mean^2 / variance by (1 - p) / p.
+extern "C" int hgv_gemm_nt16h_act_parts(int64_t M) {
+    int64_t wpb, blocks;
+    nth_grid<9>(hgv_cdiv(M > 0 ? M : 1, 16), &wpb, &blocks);
+    return (int)(wpb * blocks);
+}
+
+extern "C" int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                        const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits,
+                                        int64_t ld_bits, int relu, float scale, float* stat_partial, hipStream_t stream) {
+    HGV_REQUIRE(keep_bits != nullptr && stat_partial != nullptr, HGV_EINVAL, "gemm_nt16h_act_stats: null keep bits / partial buffer");
+    HGV_REQUIRE(M >= 2, HGV_EINVAL, "gemm_nt16h_act_stats: statistics need at least two rows");
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, keep_bits, ld_bits, relu ? 1 : 0, scale,
+                          stat_partial);
 }
 
 // hgv_gemm_nt16h that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the

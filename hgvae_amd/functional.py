@@ -396,7 +396,11 @@ class _BnStats(torch.autograd.Function):
         save_mean = torch.empty(h, dtype=torch.float32, device=y.device)
         save_rstd = torch.empty(h, dtype=torch.float32, device=y.device)
         d = y.detach()                 # same storage: overwritten behind autograd's back (y has no other reader)
-        if pre:                        # the producing projection stored d already: statistics only
+        if isinstance(pre, torch.Tensor):      # ... and left its partial column statistics: merge them
+            _lib.call("hgv_bn_stats_merge", pre.data_ptr(), pre.size(0), 16, n, h, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+                      _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked), save_mean.data_ptr(),
+                      save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), _lib.stream())
+        elif pre:                      # the producing projection stored d already: statistics only
             _lib.call("hgv_bn_stats_pre", d.data_ptr(), ld_of(d), n, h, _lib.ptr(gamma), _lib.ptr(beta), float(eps),
                       _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked), save_mean.data_ptr(),
                       save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
@@ -600,12 +604,15 @@ def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: b
     finally:
         _act_request = None
     done, _act_done = _act_done, None
-    pre = done is not None and done == (y.data_ptr(), y.size(0), y.size(1), relu, p)
+    pre = done is not None and done[:5] == (y.data_ptr(), y.size(0), y.size(1), relu, p)
     if done is not None and not pre:
         raise _lib.HgvError("a projection stored an activated level that is not this level's input")
-    if pre or (want and y.dim() == 2 and y.size(0) >= max(2, DEFER_MIN_ROWS) and y.requires_grad and y.grad_fn is not None
+    stored = pre
+    if pre:
+        pre = done[5] if done[5] is not None else True           # the partial statistics, or "stored, not summed"
+    if stored or (want and y.dim() == 2 and y.size(0) >= max(2, DEFER_MIN_ROWS) and y.requires_grad and y.grad_fn is not None
                and is_vec4(y)):
-        mask, seed, offset, ctr = (None, 0, 0, None) if pre else current_noise().dropout(y.shape, y.device)
+        mask, seed, offset, ctr = (None, 0, 0, None) if stored else current_noise().dropout(y.shape, y.device)
         momentum = bn.momentum if bn.momentum is not None else 0.1
         rm, rv, tracked = bn.running_mean, bn.running_var, bn.num_batches_tracked
         if on_branch_stream():         # see bn_act: the trunk may be updating the running statistics right now
@@ -916,6 +923,7 @@ def _assert_zero_pads(*operands) -> None:
 _act_request = None
 _act_done = None
 _nt_act = os.environ.get("HGVAE_NT_ACT", "1") != "0"            # 0: the statistics pass applies relu / dropout (A/B)
+_nt_stats = os.environ.get("HGVAE_NT_STATS", "1") != "0"        # 0: a pass of its own reads the stored level for its statistics
 
 
 def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str):
@@ -949,12 +957,19 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> 
         _lib.call("hgv_dropout_bits", m, n_out, float(p), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
         if ev:
             ev[0].record()
-        _lib.call("hgv_gemm_nt16h_act", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
+        common = (xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
                   xb.size(1) if xb is not None else 0, img.a.data_ptr(), _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out),
-                  bits.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)), _lib.stream())
+                  bits.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)))
+        partial = None
+        if _nt_stats:                  # the product also leaves the column statistics of what it stores
+            nparts = _lib.load().hgv_gemm_nt16h_act_parts(m)
+            partial = torch.empty((nparts, 2, ld_of(out)), dtype=torch.float32, device=xa.device)
+            _lib.call("hgv_gemm_nt16h_act_stats", *common, partial.data_ptr(), _lib.stream())
+        else:
+            _lib.call("hgv_gemm_nt16h_act", *common, _lib.stream())
         if ev:
             ev[1].record()
-        _act_done = (out.data_ptr(), m, n_out, relu, p)
+        _act_done = (out.data_ptr(), m, n_out, relu, p, partial)
         return out
     if ev:
         ev[0].record()

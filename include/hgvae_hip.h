@@ -367,6 +367,12 @@ int hgv_dropout_bits(int64_t N, int H, float p, uint64_t seed, uint64_t offset, 
 int hgv_bn_stats_pre(const float* d, int64_t ldd, int64_t N, int H, const float* gamma, const float* beta, float eps,
                      float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
                      float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
+
+/* The merge step of the level statistics on its own: partial[nparts][2][Hp] = (mean, M2) of part p over the rows of the
+ * group_rows-row groups p, p + nparts, ... of [0, N).  Writes what hgv_bn_stats_act writes. */
+int hgv_bn_stats_merge(const float* partial, int nparts, int group_rows, int64_t N, int H, const float* gamma, const float* beta,
+                       float eps, float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked,
+                       float* save_mean, float* save_rstd, float* col_s, float* col_t, hgv_stream_t stream);
 int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t sk1, int K1, const float* cs1, const float* ct1,
                                int indicator1, const float* W2, int64_t sn2, int64_t sk2, int K2, const float* cs2,
                                const float* ct2, int N, const float* bias_in, float* bias_out, void* out, hgv_stream_t stream);
@@ -435,6 +441,16 @@ int hgv_gemm_nt16h_act_supported(int N, int K1, int K2);
 int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                        const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits, int64_t ld_bits,
                        int relu, float scale, hgv_stream_t stream);
+
+/* hgv_gemm_nt16h_act that also leaves the column statistics of what it stored (the batch statistics of the level's
+ * BatchNorm1d, gvae/gvae_skipcon.py:107): stat_partial[parts][2][Hp] (Hp = 4 * ceil(N / 4), parts =
+ * hgv_gemm_nt16h_act_parts(M)) receives per part p the (mean, M2) over the rows of the 16-row groups p, p + parts, ... ;
+ * hgv_bn_stats_merge(partial, parts, 16, M, N, ...) finishes them.  Plain fp32 sums of d and d^2 per part (M2 formed in
+ * fp64): meant for levels behind a dropout of rate p >= 0.2, whose zeros bound mean^2 / variance of d by (1 - p) / p. */
+int hgv_gemm_nt16h_act_parts(int64_t M);
+int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                             const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits,
+                             int64_t ld_bits, int relu, float scale, float* stat_partial, hgv_stream_t stream);
 int hgv_gemm_nt16_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                         const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
                         hgv_stream_t stream);
