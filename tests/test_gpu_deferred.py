@@ -237,6 +237,39 @@ def test_projection_stores_the_activated_level_itself(op, relu, n_out, in_produc
         assert same(u, v), (float((u - v).abs().max()), float(v.abs().max()))
 
 
+@pytest.mark.parametrize("p,offset", [(0.5, 0.0), (0.5, 300.0), (0.2, 300.0), (0.5, -1e4)])
+@pytest.mark.parametrize("n", [70001, 130])
+def test_in_product_statistics_with_a_large_common_offset(p, offset, n, monkeypatch):
+    """The column sums taken inside the product are plain sums of d and d^2 per wave: a pre-activation whose mean is
+    hundreds of standard deviations from zero (a large bias) must still give the batch statistics of the shifted sums of
+    the statistics kernel - dropout's zeros are part of the variance, so mean^2 / variance of d stays below (1 - p) / p."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    k, n_out = 138, 138
+    gen = torch.Generator(device=dev()).manual_seed(int(offset) % 1000 + n)
+    xa0 = _rand((n, k), gen)
+    w = _rand((n_out, k), gen, 0.1)
+    bias = torch.full((n_out,), offset, device=dev()) + _rand((n_out,), gen)
+    out = []
+    for in_product in (True, False):
+        monkeypatch.setattr(Fn, "_nt_stats", in_product)
+        bn = _bn(n_out, torch.Generator(device=dev()).manual_seed(5))
+        xa = xa0.clone().requires_grad_(True)
+        with use_noise(PhiloxNoise(77)), Fn.deferred_levels():
+            lvl = Fn.bn_level(lambda: Fn.dual_linear(xa, w, None, None, bias), bn, False, p, True, act_ok=True)
+        assert isinstance(lvl, Fn.Deferred)
+        out.append((lvl.mean.clone(), lvl.rstd.clone(), lvl.s.clone(), lvl.t.clone(), bn.running_var.clone(), lvl.d.detach().clone()))
+    a, b = out
+    assert torch.equal(a[5].view(torch.int32), b[5].view(torch.int32))
+    d64 = b[5][:, :n_out].double()
+    mean64, var64 = d64.mean(0), d64.var(0, unbiased=False)
+    for got in (a, b):
+        assert float(((got[0].double() - mean64).abs() / var64.sqrt()).max()) <= 2e-6
+        assert float((got[1].double() * (var64 + bn.eps).sqrt() - 1).abs().max()) <= 3e-6
+    assert float(((a[2] - b[2]).abs() / b[2].abs().clamp_min(1e-30)).max()) <= 5e-6
+    assert float(((a[3].double() - b[3].double()).abs()).max()) <= 5e-6 * max(1.0, float((mean64.abs() * b[2].abs().double()[:n_out]).max()))
+
+
 @pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
 def test_sage_convolution_on_a_deferred_operand(first, h_in):
     """SAGEConv over (d, s, t) = SAGEConv over the written-out d * s + t: forward, input gradient (with respect to `out`),
