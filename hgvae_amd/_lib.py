@@ -46,6 +46,10 @@ SIGNATURES = {
                               _vp, _i64, _vp, _vp, _vp]),
     "hgv_gat_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _f32, _f32,
                               _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "hgv_gat_fwd_long": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _f32, _f32, _vp, _u64, _u64, _vp, _vp,
+                              _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "hgv_gat_bwd_long": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _f32, _f32,
+                              _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "hgv_topk_ws": (_sz, [_i64]),
     "hgv_topk_perm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _sz, _vp]),
     "hgv_filter_adj_ws": (_sz, [_i64, _i64]),

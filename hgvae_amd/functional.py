@@ -1872,6 +1872,9 @@ def mse_loss(recon: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 # single-head graph attention (edge softmax + weighted aggregation)
 # --------------------------------------------------------------------------------------
+_gat_long = os.environ.get("HGVAE_GAT_LONG", "1") != "0"        # 0: hub rows stay with their lane group (A/B measurements)
+
+
 class _GatAggregate(torch.autograd.Function):
     """out_i = sum_k dropout(softmax_i(leaky_relu(a_src[col_k] + a_dst[i])))_k * xw[col_k] (+ bias)
 
@@ -1895,10 +1898,12 @@ class _GatAggregate(torch.autograd.Function):
         row_den = torch.empty(n, dtype=torch.float32, device=dev)
         out = new_padded(n, c, dev, zero_pad=False)
         lda = ld_of(ab)
-        _lib.call("hgv_gat_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n, xw.data_ptr(), ld_of(xw),
+        lr = csr.long_rows(n)          # hub rows go to a workgroup each
+        _lib.call("hgv_gat_fwd_long" if _gat_long else "hgv_gat_fwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), n, xw.data_ptr(), ld_of(xw),
                   c, ab.data_ptr(), lda, ab.data_ptr() + 4, lda, float(slope), float(p),
                   _lib.ptr(mask), seed, offset, ctr, _lib.ptr(bias), out.data_ptr(), ld_of(out), row_max.data_ptr(),
-                  row_den.data_ptr(), _lib.stream())
+                  row_den.data_ptr(), *((lr.threshold, lr.rows.data_ptr(), lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0)
+                                        if _gat_long else ()), _lib.stream())
         ctx.lg, ctx.cfg = lg, (slope, p, seed, offset, ctr)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(xw, att, ab, row_max, row_den, mask)
@@ -1919,12 +1924,16 @@ class _GatAggregate(torch.autograd.Function):
         att_p.copy_(att.detach())
         gxw = new_padded(n, c, dev, zero_pad=False)
         lda, ldd = ld_of(ab), ld_of(da)
-        _lib.call("hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), csr_t.rowptr.data_ptr(),
+        lr, lr_t = csr.long_rows(n), csr_t.long_rows(n)
+        _lib.call("hgv_gat_bwd_long" if _gat_long else "hgv_gat_bwd", csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.perm.data_ptr(), csr_t.rowptr.data_ptr(),
                   csr_t.col.data_ptr(), csr_t.perm.data_ptr(), n, g.data_ptr(), ld_of(g), xw.data_ptr(), ld_of(xw), c,
                   ab.data_ptr(), lda, ab.data_ptr() + 4, lda, float(slope), float(p),
                   _lib.ptr(mask), seed, offset, ctr, row_max.data_ptr(), row_den.data_ptr(), scratch.data_ptr(),
                   gxw.data_ptr(), ld_of(gxw), da.data_ptr(), da.data_ptr() + 4, ldd, att_p.data_ptr(),
-                  att_p.data_ptr() + 4 * ld_of(att_p), _lib.stream())
+                  att_p.data_ptr() + 4 * ld_of(att_p),
+                  *((lr.threshold, lr.rows.data_ptr(), lr.count.data_ptr(), lr.cap, 1 if lr.maybe_any() else 0,
+                     lr_t.threshold, lr_t.rows.data_ptr(), lr_t.count.data_ptr(), lr_t.cap, 1 if lr_t.maybe_any() else 0)
+                    if _gat_long else ()), _lib.stream())
         gatt = None
         if ctx.needs_input_grad[1]:
             gatt, _ = _gemm_tn(da, xw, False)                          # [2, C] = [da_src | da_dst]^T xw

@@ -228,6 +228,26 @@ int hgv_gat_bwd(const int32_t* rowptr, const int32_t* col, const int32_t* perm, 
                 const float* row_den, float* S, float* gxw, int64_t ldgx, float* da_src, float* da_dst, int64_t ld_da,
                 const float* att_src, const float* att_dst, hgv_stream_t stream);
 
+/* hgv_gat_fwd / hgv_gat_bwd with hub rows handled by a workgroup each (GATConv over graphs whose degrees are very uneven,
+ * gvae/gvae_skipcon_attention.py:109): rows with more than long_threshold (> 0) entries - listed by hgv_csr_long_rows with
+ * the same threshold in long_rows[min(*long_count, long_cap)] - are left out of the lane-group kernels and summed in
+ * eight in-order parts by a 512-thread workgroup (same value to rounding; no atomics).  run_long_pass = 0 skips the pass
+ * when the caller knows the list is empty.  The backward pass takes one list per CSR (by target; by source: suffix _t). */
+int hgv_gat_fwd_long(const int32_t* rowptr, const int32_t* col, const int32_t* perm, int64_t N, const float* xw, int64_t ldx,
+                     int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope, float p,
+                     const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, const float* bias,
+                     float* out, int64_t ldo, float* row_max, float* row_den, int long_threshold, const int32_t* long_rows,
+                     const int32_t* long_count, int long_cap, int run_long_pass, hgv_stream_t stream);
+int hgv_gat_bwd_long(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* rowptr_t,
+                     const int32_t* col_t, const int32_t* perm_t, int64_t N, const float* g, int64_t ldg, const float* xw,
+                     int64_t ldx, int C, const float* a_src, int64_t ld_src, const float* a_dst, int64_t ld_dst, float slope,
+                     float p, const uint8_t* mask, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                     const float* row_max, const float* row_den, float* S, float* gxw, int64_t ldgx, float* da_src,
+                     float* da_dst, int64_t ld_da, const float* att_src, const float* att_dst, int long_threshold,
+                     const int32_t* long_rows, const int32_t* long_count, int long_cap, int run_long_pass,
+                     int long_threshold_t, const int32_t* long_rows_t, const int32_t* long_count_t, int long_cap_t,
+                     int run_long_pass_t, hgv_stream_t stream);
+
 /* ---- SAGPooling: autoencoder/vae_with_pool.py:25,36,39 and :42-50;
  *      autoencoder/vae_custom_pool.py:56-58 ------------------------------------------------
  * hgv_topk_perm: per graph (ascending graph id) the k[g] highest-scoring nodes, descending score,

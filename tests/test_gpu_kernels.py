@@ -376,6 +376,72 @@ def test_gat_forward_backward(graph, p):
         close(prm.grad, refp[name].grad, BWD_RTOL)
 
 
+@pytest.mark.parametrize("c,p", [(64, 0.0), (138, 0.49), (256, 0.3)])
+def test_gat_hub_rows_take_the_workgroup_kernels(c, p):
+    """A node that 3 000 others point to and that points to 2 500 others (far above 4 x the mean degree): its row of the
+    by-target CSR and its row of the by-source CSR go through k_gat_*_long.  Forward and every gradient against the
+    oracle, and against the lane-group kernels on the same inputs."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd import nn as HN
+    from hgvae_amd.noise import NoiseTape, use_noise
+    gen = torch.Generator().manual_seed(77 + c)
+    n = 4000
+    base = torch.randint(0, n, (2, 12000), generator=gen)
+    into_hub = torch.stack([torch.randperm(n, generator=gen)[:3000], torch.full((3000,), 17)])
+    from_hub = torch.stack([torch.full((2500,), 17), torch.randperm(n, generator=gen)[:2500]])
+    second = torch.stack([torch.randperm(n, generator=gen)[:700], torch.full((700,), 3999)])
+    ei = torch.cat([base, into_hub, from_hub, second], 1)
+    torch.manual_seed(4)
+    ref = O.GATConv(c, c, heads=1, dropout=p).train()
+    mod = _copy_params(HN.GATConv(c, c, heads=1, dropout=p), ref).train()
+    n_edges = int((ei[0] != ei[1]).sum()) + n
+    mask = torch.bernoulli(torch.full((n_edges, 1), 1 - p), generator=gen)
+    x = torch.randn(n, c, generator=gen, requires_grad=True)
+    gout = torch.randn(n, c, generator=gen)
+    out_ref = ref(x, ei, O.NoiseTape([mask]))
+    out_ref.backward(gout)
+    results = []
+    names = []
+    real_call = Fn._lib.call
+
+    def spy_call(name, *a, _real=real_call):
+        names.append(name)
+        return _real(name, *a)
+    for long_rows in (True, False):
+        Fn._gat_long = long_rows
+        Fn._lib.call = spy_call
+        try:
+            mod.zero_grad()
+            xd = x.detach().to(dev()).requires_grad_(True)
+            with use_noise(NoiseTape([mask])):
+                out = mod(xd, ei.to(dev()))
+            out.backward(gout.to(dev()))
+        finally:
+            Fn._gat_long = True
+            Fn._lib.call = real_call
+        results.append((out.detach().clone(), xd.grad.clone(), {k: v.grad.clone() for k, v in mod.named_parameters()}))
+        if long_rows:
+            assert "hgv_gat_fwd_long" in names and "hgv_gat_bwd_long" in names
+            close(out, out_ref, FWD_RTOL)
+            close(xd.grad, x.grad, BWD_RTOL)
+            refp = dict(ref.named_parameters())
+            for name, prm in mod.named_parameters():
+                close(prm.grad, refp[name].grad, BWD_RTOL)
+    (oa, ga, pa), (ob, gb, pb) = results
+    assert float((oa - ob).abs().max()) <= 2e-6 * float(ob.abs().max())
+    assert float((ga - gb).abs().max()) <= 1e-5 * float(gb.abs().max())
+    for k in pb:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * max(float(pb[k].abs().max()), 1e-30), k
+    # the hub rows are on the lists the kernels were given
+    from hgvae_amd.graph import graph_of
+    eid = ei.to(dev())                                 # the graph keeps only a weak reference to its edge list
+    lg = graph_of(eid, n).with_self_loops()
+    for csr in (lg.by_dst, lg.by_src):
+        lr = csr.long_rows(n)
+        rows = set(lr.rows[: int(lr.count)].tolist())
+        assert 17 in rows, (lr.threshold, rows)
+
+
 def test_gat_attention_rows_sum_to_one_known_answer():
     """2-edge graph 0->2, 1->2 plus loops: with a_src = a_dst = 0 every alpha is 1/row length."""
     from hgvae_amd import functional as Fn
