@@ -104,7 +104,7 @@ SIGNATURES = {
     "hgv_gemm_nt16h_act_stats": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp,
                                            _vp]),
     "hgv_bn_stats_merge": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "hgv_dropout_bits": (C.c_int, [_i64, _i32, _f32, _u64, _u64, _vp, _vp, _i64, _vp]),
+    "hgv_dropout_bits": (C.c_int, [_i64, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i64, _vp]),
     "hgv_bn_stats_pre": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hgv_gemm_nt16_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hgv_distance_matrix": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),

@@ -914,14 +914,15 @@ __global__ __launch_bounds__(256) void k_dropout_bits(const EpArgs a, uint32_t* 
 }
 }  // namespace
 
-// Keep bits of one Philox dropout call over [N, H]: the decisions hgv_bn_stats_act / hgv_bn_act_fwd take for the same
-// (p, seed, offset, offset_dev).  bits: [N, ld_bits] 32-bit words, ld_bits >= ceil(4 * ceil(H / 4) / 32); bits of columns
+// Keep bits of one dropout call over [N, H]: the decisions hgv_bn_stats_act / hgv_bn_act_fwd take for the same explicit
+// mask ([N, H] bytes, non-zero = keep) or, with mask == nullptr, the same Philox (p, seed, offset, offset_dev).
+// bits: [N, ld_bits] 32-bit words, ld_bits >= ceil(4 * ceil(H / 4) / 32); bits of columns
 // in [H, 32 * ld_bits) covered by a chunk are set (kept).  For projections that store the activated level themselves.
-extern "C" int hgv_dropout_bits(int64_t N, int H, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                                uint32_t* bits, int64_t ld_bits, hipStream_t stream) {
+extern "C" int hgv_dropout_bits(int64_t N, int H, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                                const uint64_t* offset_dev, uint32_t* bits, int64_t ld_bits, hipStream_t stream) {
     EpArgs a; int nb;
     HGV_REQUIRE(bits != nullptr && p > 0.f, HGV_EINVAL, "dropout_bits: null buffer or p = 0");
-    int rc = make_args(a, reinterpret_cast<const float*>(bits), H, N, H, 0, p, nullptr, seed, offset, offset_dev, &nb);
+    int rc = make_args(a, reinterpret_cast<const float*>(bits), H, N, H, 0, p, mask, seed, offset, offset_dev, &nb);
     if (rc != HGV_OK) return rc;
     const int W = (a.CH * 4 + 31) / 32;
     HGV_REQUIRE(ld_bits >= W, HGV_EINVAL, "dropout_bits: %lld words per row, %d needed", (long long)ld_bits, W);

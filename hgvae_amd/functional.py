@@ -598,7 +598,7 @@ def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: b
     global _act_request, _act_done
     want = _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P
     _act_done = None
-    _act_request = (relu, p) if (want and act_ok and _nt_act and noise_is_counter_based()) else None
+    _act_request = (relu, p) if (want and act_ok and _nt_act) else None
     try:
         y = plain(make_y())
     finally:
@@ -926,17 +926,15 @@ _nt_act = os.environ.get("HGVAE_NT_ACT", "1") != "0"            # 0: the statist
 _nt_stats = os.environ.get("HGVAE_NT_STATS", "1") != "0"        # 0: a pass of its own reads the stored level for its statistics
 
 
-def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str):
+def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str, device):
     """(relu, p, scale, bits, seed/offset record) for a projection that stores the activated level, or None."""
     global _act_request
     req, _act_request = _act_request, None
     if req is None or kind != "f16x3" or m < max(2, DEFER_MIN_ROWS) or not _lib.load().hgv_gemm_nt16h_act_supported(n_out, k1, k2):
         return None
     relu, p = req
-    mask, seed, offset, ctr = current_noise().dropout((m, n_out), None)
-    if mask is not None:
-        raise _lib.HgvError("activated projection store: counter-based noise expected")
-    return relu, p, seed, offset, ctr
+    mask, seed, offset, ctr = current_noise().dropout((m, n_out), device)
+    return relu, p, mask, seed, offset, ctr
 
 
 def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> torch.Tensor:
@@ -949,12 +947,13 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> 
         _assert_zero_pads(xa, xb)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
-    act = _take_act(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0, img.kind) if (level_out and _act_request is not None) else None
+    act = (_take_act(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0, img.kind, xa.device)
+           if (level_out and _act_request is not None) else None)
     if act is not None:
-        relu, p, seed, offset, ctr = act
+        relu, p, mask, seed, offset, ctr = act
         words = (ld_of(out) + 31) // 32
         bits = torch.empty((m, words), dtype=torch.int32, device=xa.device)
-        _lib.call("hgv_dropout_bits", m, n_out, float(p), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+        _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
         if ev:
             ev[0].record()
         common = (xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,

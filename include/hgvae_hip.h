@@ -376,11 +376,12 @@ int hgv_bn_stats_act(float* y, int64_t ldy, int64_t N, int H, int relu, float p,
                      float* running_mean, float* running_var, float momentum, int64_t* num_batches_tracked, float* save_mean,
                      float* save_rstd, float* col_s, float* col_t, void* ws, size_t ws_bytes, hgv_stream_t stream);
 
-/* Keep bits of one Philox dropout call over [N, H]: the decisions hgv_bn_stats_act / hgv_bn_act_fwd take for the same
- * (p, seed, offset, offset_dev) - torch.nn.Dropout of the reference's level tails.  bits: [N, ld_bits] 32-bit words,
- * ld_bits >= ceil(4 * ceil(H / 4) / 32); bit c & 31 of word c >> 5 = element (row, c) is kept. */
-int hgv_dropout_bits(int64_t N, int H, float p, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, uint32_t* bits,
-                     int64_t ld_bits, hgv_stream_t stream);
+/* Keep bits of one dropout call over [N, H] - torch.nn.Dropout of the reference's level tails: the decisions
+ * hgv_bn_stats_act / hgv_bn_act_fwd take for the same explicit mask ([N, H] bytes, non-zero = keep) or, with mask ==
+ * NULL, the same Philox (p, seed, offset, offset_dev).  bits: [N, ld_bits] 32-bit words, ld_bits >= ceil(4 * ceil(H / 4)
+ * / 32); bit c & 31 of word c >> 5 = element (row, c) is kept. */
+int hgv_dropout_bits(int64_t N, int H, float p, const uint8_t* mask, uint64_t seed, uint64_t offset,
+                     const uint64_t* offset_dev, uint32_t* bits, int64_t ld_bits, hgv_stream_t stream);
 
 /* The statistics half of hgv_bn_stats_act for a matrix that already holds d = dropout(relu(y)) (hgv_gemm_nt16h_act stored
  * it): one read, no write; mean / rstd / col_s / col_t / running statistics equal hgv_bn_stats_act's bit for bit. */
