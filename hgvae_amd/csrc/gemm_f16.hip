@@ -182,10 +182,10 @@ struct NtHArgs {
     // c >> 5 of the row's act_ldb words; hgv_dropout_bits writes them).  A dropped element is stored as -0.0f when
     // there is no relu in front and a kept zero as +0.0f, so later passes read relu and dropout off the stored values.
     const uint32_t* act_bits; int64_t act_ldb; int act_relu; float act_scale;
-    // ... and its column statistics (kernels instantiated with ACT = 2): every wave leaves (mean, M2) of the rows it
-    // stored in stat_partial[wave][2][stat_hp] - wave w of W owns the 16-row tiles w, w + W, ... - for the merge that
-    // the statistics kernels of the level tail use.  The sums are plain sums of d and d^2 over the few hundred rows of a
-    // wave, M2 = S2 - S1^2 / n formed in fp64: behind a dropout of rate p the stored values satisfy mean^2 / variance <=
+    // ... and its column statistics (kernels instantiated with ACT = 2): every workgroup leaves (mean, M2) of the rows it
+    // stored in stat_partial[workgroup][2][stat_hp] - workgroup b of B owns the 16-row tiles b, b + B, ... - for the merge
+    // that the statistics kernels of the level tail use.  The sums are plain fp32 sums of d and d^2 over the few hundred rows
+    // of a wave, added over the waves and turned into M2 = S2 - S1^2 / n in fp64: behind a dropout of rate p the stored values satisfy mean^2 / variance <=
     // (1 - p) / p (the zeros it inserts are part of the variance), so nothing cancels as long as p is not small -
     // callers use this form from p = 0.2 upwards
     float* stat_partial; int stat_hp;
@@ -509,28 +509,33 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     }
     if (ACT == 0 && a.paced && lane == 0) __hip_atomic_store(pace_mine, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (ACT == 2 && NT == 9) {
-        // which of the 36 values (v = 4 n + r: column 16 n + 4 kq + r) the lane's three sums belong to: the halves kept above
-        const int b3 = (i >> 3) & 1, b2 = (i >> 2) & 1, b1 = (i >> 1) & 1, b0 = i & 1;
-        const int len_c = b1 ? 4 : 5;
-        const int base = 18 * b3 + 9 * b2 + 5 * b1 + 3 * b0;
-        const int len = b0 ? len_c - 3 : 3;
-        // rows of this wave: tiles gw, gw + nw, ...; only the last tile of the matrix may be short
-        const int64_t last = a.ntiles - 1;
-        const double nrows = (double)(my_tiles * 16 - ((my_tiles > 0 && last % nw == gw) ? a.ntiles * 16 - a.M : 0));
-        float* dst = a.stat_partial + gw * 2 * a.stat_hp;
+        // the waves of a workgroup hold sums for the same columns lane by lane: add them in wave order through LDS (the
+        // weight image is dead by now) and leave one (mean, M2) pair per workgroup.  A workgroup owns the 16-row tiles
+        // b, b + B, b + 2 B, ... (b = its rank among B workgroups); only the last tile of the matrix may be short.
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds_raw);            // [waves][64][6]
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int v = base + q;
-            const int col = 16 * (v >> 2) + 4 * kq + (v & 3);
-            if (q < len && col < a.stat_hp) {
-                float mean = 0.f, m2 = 0.f;
-                if (my_tiles > 0) {
-                    const double s1 = (double)st1[q], s2 = (double)st2[q];
-                    mean = (float)(s1 / nrows);
-                    m2 = (float)(s2 - s1 * s1 / nrows);
+        for (int q = 0; q < 3; ++q) { red[(wib * 64 + lane) * 6 + q] = st1[q]; red[(wib * 64 + lane) * 6 + 3 + q] = st2[q]; }
+        __syncthreads();
+        if (wib == 0) {
+            // which of the 36 values (v = 4 n + r: column 16 n + 4 kq + r) the lane's three sums belong to: the halves kept above
+            const int b3 = (i >> 3) & 1, b2 = (i >> 2) & 1, b1 = (i >> 1) & 1, b0 = i & 1;
+            const int len_c = b1 ? 4 : 5;
+            const int base = 18 * b3 + 9 * b2 + 5 * b1 + 3 * b0;
+            const int len = b0 ? len_c - 3 : 3;
+            const int64_t groups = wg_rank < a.ntiles ? (a.ntiles - 1 - wg_rank) / wgs + 1 : 0;
+            const double nrows = (double)(groups * 16 - ((groups > 0 && (a.ntiles - 1) % wgs == wg_rank) ? a.ntiles * 16 - a.M : 0));
+            float* dst = a.stat_partial + (int64_t)wg_rank * 2 * a.stat_hp;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int v = base + q;
+                const int col = 16 * (v >> 2) + 4 * kq + (v & 3);
+                if (q < len && col < a.stat_hp) {
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int w2 = 0; w2 < wpb; ++w2) { s1 += (double)red[(w2 * 64 + lane) * 6 + q]; s2 += (double)red[(w2 * 64 + lane) * 6 + 3 + q]; }
+                    dst[col] = groups > 0 ? (float)(s1 / nrows) : 0.f;
+                    dst[a.stat_hp + col] = groups > 0 ? (float)(s2 - s1 * s1 / nrows) : 0.f;
                 }
-                dst[col] = mean;
-                dst[a.stat_hp + col] = m2;
             }
         }
     }
@@ -957,7 +962,7 @@ extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const f
 extern "C" int hgv_gemm_nt16h_act_parts(int64_t M) {
     int64_t wpb, blocks;
     nth_grid<9>(hgv_cdiv(M > 0 ? M : 1, 16), &wpb, &blocks);
-    return (int)(wpb * blocks);
+    return (int)blocks;
 }
 
 extern "C" int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,

@@ -444,9 +444,24 @@ def test_counter_noise_step_defers_the_shared_first_level_for_both_passes(varian
 
 @pytest.mark.parametrize("graph", ["paths", "random", "ragged", "edgeless"])
 def test_skipcon_step_with_deferred_levels_matches_the_oracle(graph):
-    """The oracle comparisons of tests/test_gpu_model.py, run with deferral at every size (the fixture of this file)."""
+    """The oracle comparisons of tests/test_gpu_model.py, run with deferral at every size (the fixture of this file): with
+    the oracle's explicit masks the step takes the same kernels as production - the projections store the activated
+    levels and their column sums, the backward sums come from the consumers' products."""
     import test_gpu_model as M
-    M.test_skipcon_train_step_matches_oracle(graph)
+    from hgvae_amd import functional as Fn
+    names = []
+    real_call = Fn._lib.call
+
+    def spy_call(name, *a, _real=real_call):
+        names.append(name)
+        return _real(name, *a)
+    Fn._lib.call = spy_call
+    try:
+        M.test_skipcon_train_step_matches_oracle(graph)
+    finally:
+        Fn._lib.call = real_call
+    for expected in ("hgv_dropout_bits", "hgv_gemm_nt16h_act_stats", "hgv_bn_stats_merge", "hgv_bn_act_bwd_pre_alg", "hgv_agg_fwd_ind"):
+        assert expected in names, expected
 
 
 def test_other_variants_with_deferred_levels_match_the_oracle():
