@@ -599,10 +599,12 @@ def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: b
     want = _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P
     _act_done = None
     _act_request = (relu, p) if (want and act_ok and _nt_act) else None
+    global _act_ready
     try:
         y = plain(make_y())
     finally:
         _act_request = None
+        _act_ready = None
     done, _act_done = _act_done, None
     pre = done is not None and done[:5] == (y.data_ptr(), y.size(0), y.size(1), relu, p)
     if done is not None and not pre:
@@ -937,23 +939,65 @@ def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str, device):
     return relu, p, mask, seed, offset, ctr
 
 
+_act_ready = None            # keep bits of a pending activated store, already being generated on the side stream
+_bits_early = os.environ.get("HGVAE_BITS_EARLY", "1") != "0"    # 0: the keep bits are generated right in front of the product
+_side_streams: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _start_level_bits(m: int, n_out: int, k1: int, k2: int, device) -> None:
+    """Called by an operator that has other launches in front of its level product (the aggregation of a SAGEConv): the
+    keep bits depend on nothing but the noise stream, so their kernel - bound by the generator's integer multiplies - goes
+    to a side stream now and runs beside those launches; the product waits for it."""
+    global _act_ready
+    if _act_request is None or not _bits_early or torch.cuda.is_current_stream_capturing() or on_branch_stream():
+        return
+    act = _take_act(m, n_out, k1, k2, "f16x3", device)
+    if act is None:
+        return
+    relu, p, mask, seed, offset, ctr = act
+    words = ((n_out + 3) // 4 * 4 + 31) // 32
+    bits = torch.empty((m, words), dtype=torch.int32, device=device)
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)                 # the buffer may be a recycled block whose last use is still queued on the main stream
+    with torch.cuda.stream(side):
+        _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+        done = side.record_event()
+    bits.record_stream(side)
+    _act_ready = (m, n_out, relu, p, bits, words, done)
+
+
 def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
     xa / xb must already be in the padded layout.  ``level_out``: this product is the pre-activation a level asked for
     (see ``_act_request``)."""
-    global _act_done
+    global _act_done, _act_ready
     m = xa.size(0)
     if _CHECK_PADS:
         _assert_zero_pads(xa, xb)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
+    ready, _act_ready = (_act_ready, None) if level_out else (None, _act_ready)
     act = (_take_act(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0, img.kind, xa.device)
-           if (level_out and _act_request is not None) else None)
-    if act is not None:
-        relu, p, mask, seed, offset, ctr = act
-        words = (ld_of(out) + 31) // 32
-        bits = torch.empty((m, words), dtype=torch.int32, device=xa.device)
-        _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+           if (level_out and ready is None and _act_request is not None) else None)
+    if ready is not None and (ready[0], ready[1]) != (m, n_out):
+        raise _lib.HgvError("keep bits were prepared for another product")
+    if ready is not None or act is not None:
+        if ready is not None:
+            _, _, relu, p, bits, words, done = ready
+            torch.cuda.current_stream(xa.device).wait_event(done)
+        else:
+            relu, p, mask, seed, offset, ctr = act
+            words = (ld_of(out) + 31) // 32
+            bits = torch.empty((m, words), dtype=torch.int32, device=xa.device)
+            _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
         if ev:
             ev[0].record()
         common = (xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
@@ -1425,6 +1469,7 @@ class _SageConv(torch.autograd.Function):
             # weight wl t (mean_j(d_j s + t) = mean_j(d_j) s + t * indicator); without a pad column the aggregation
             # applies s / t to its finished rows itself
             ind = aff is not None and n_in % 4 != 0
+            _start_level_bits(n, n_out, n_in + (1 if ind else 0), n_in, x.device)
             agg = new_padded(n, n_in, x.device, zero_pad=False)
             if ind:
                 _agg_ind_launch(graph.by_dst, n, x, n_in, agg, n_in)
