@@ -126,6 +126,7 @@ SIGNATURES = {
     "hgv_gemm_tn_gg_ws": (_sz, [_i64, _i32, _i32]),
     "hgv_gemm_tn_gg": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _sz,
                                  _vp]),
+    "hgv_gemm_tn16_gg": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp, _i32, _vp, _sz, _vp]),
     "hgv_loss_ws": (_sz, []),
     "hgv_reparam_fwd": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _u64, _u64, _vp, _vp, _i64, _vp, _vp]),
     "hgv_reparam_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),

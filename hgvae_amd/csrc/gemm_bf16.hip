@@ -695,6 +695,7 @@ struct Tn16Args {
     float* bias_partial;       // [ngrp][set][9][4][64], written by the workgroups of k group 0 (null: no bias)
     int paced;                 // two k groups, one n group: the two workgroups of a row slice share an XCD and walk G in step
     int pace_slot;             // which copy of the progress counters a paced launch uses
+    const float* G2; int64_t ldg2; int n_split;   // optional: columns >= n_split (a multiple of 4) of G come from G2 (column n - n_split)
 };
 
 __device__ __forceinline__ int t16_slot(int r) { return (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1); }
@@ -731,9 +732,10 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
         const int row = rem / 36, c4 = rem - 36 * row, col = 4 * c4;
         const int width = isa ? k_w : n_w;
         const int ceff = col < (width + 3) / 4 * 4 ? col : 0;
-        ld[u] = isa ? lda : a.ldg;
+        const bool g2 = !isa && a.G2 != nullptr && n_off + ceff >= a.n_split;
+        ld[u] = isa ? lda : (g2 ? a.ldg2 : a.ldg);
         srow[u] = row;
-        src[u] = (isa ? Ab + k_off : a.G + n_off) + (int64_t)row * ld[u] + ceff;
+        src[u] = (isa ? Ab + k_off : (g2 ? a.G2 - a.n_split : a.G) + n_off) + (int64_t)row * ld[u] + ceff;
         waddr[u] = (isa * 9 + (col >> 4)) * T16_PANEL + t16_slot(row) * 32 + (col & 15) * 2;
     }
     f32x4 stage[3];
@@ -1303,19 +1305,23 @@ extern "C" size_t hgv_gemm_tn16_ws(int64_t M, int N, int K1, int K2) {
 // GW1[N,K1] (+)= G^T A1, GW2[N,K2] (+)= G^T A2 (A2 / GW2 null for a single product), gbias[N] (+)= column sums of G.
 static int gemm_tn16_any(bool f16, const float* G, int64_t ldg, int N, const float* A1, int64_t lda1, int K1, float* GW1, int64_t ldgw1,
                         const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
-                        int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
+                        int accumulate, void* ws, size_t ws_bytes, hipStream_t stream, const float* Gb = nullptr,
+                        int64_t ldgb = 0, int n_split = 0) {
     if (!A2) K2 = 0;
     HGV_REQUIRE(M > 0 && N > 0 && K1 > 0 && (A2 ? K2 > 0 && GW2 : true), HGV_EINVAL, "gemm_tn16: bad sizes");
     const Tn16Plan p = tn16_plan(M, N, K1, K2);
     HGV_REQUIRE(p.ok, HGV_EUNSUPPORTED, "gemm_tn16: shape %lld x %d x (%d + %d) is not supported", (long long)M, N, K1, K2);
     HGV_REQUIRE(G && A1 && GW1 && ws && hgv_aligned(G, 16) && hgv_aligned(A1, 16) && ldg % 4 == 0 && lda1 % 4 == 0 &&
-                ldg >= N && lda1 >= K1 && ldgw1 >= K1, HGV_EINVAL, "gemm_tn16: null / misaligned buffer or bad leading dimension");
+                ldg >= (Gb ? n_split : N) && lda1 >= K1 && ldgw1 >= K1, HGV_EINVAL, "gemm_tn16: null / misaligned buffer or bad leading dimension");
     if (A2) HGV_REQUIRE(hgv_aligned(A2, 16) && lda2 % 4 == 0 && lda2 >= K2 && ldgw2 >= K2, HGV_EINVAL,
                         "gemm_tn16: misaligned second source or bad leading dimension");
     HGV_REQUIRE(ws_bytes >= hgv_gemm_tn16_ws(M, N, K1, K2) && hgv_aligned(ws, 256), HGV_EWORKSPACE, "gemm_tn16: workspace too small or misaligned");
     Tr16Args r{};
     Tn16Args& a = r.t;
     a.G = G; a.ldg = ldg; a.N = N;
+    a.G2 = Gb; a.ldg2 = ldgb; a.n_split = n_split;
+    if (Gb) HGV_REQUIRE(!f16 && n_split > 0 && n_split % 4 == 0 && n_split < N && hgv_aligned(Gb, 16) && ldgb % 4 == 0 && ldgb >= N - n_split,
+                        HGV_EINVAL, "gemm_tn16_gg: bad second gradient matrix");
     a.A[0] = A1; a.lda[0] = lda1; a.K[0] = K1; a.A[1] = A2 ? A2 : A1; a.lda[1] = A2 ? lda2 : lda1; a.K[1] = K2;
     a.kg0 = p.kg0; a.ngrps = p.ngrps; a.kgrps = p.kgrps; a.M = M; a.steps = p.steps; a.sets = p.sets;
     // pacing pays once G no longer stays in the memory-side cache between its two reads; it needs every workgroup resident
@@ -1354,4 +1360,15 @@ extern "C" int hgv_gemm_tn16h(const float* G, int64_t ldg, int N, const float* A
                               const float* A2, int64_t lda2, int K2, float* GW2, int64_t ldgw2, int64_t M, float* gbias,
                               int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
     return gemm_tn16_any(true, G, ldg, N, A1, lda1, K1, GW1, ldgw1, A2, lda2, K2, GW2, ldgw2, M, gbias, accumulate, ws, ws_bytes, stream);
+}
+
+// One weight-gradient product for two gradient matrices of the same width N side by side: GW[2N, K] (+)= [Ga | Gb]^T A,
+// gbias[2N] (+)= the column sums of Ga, then of Gb (N a multiple of 4; shapes as hgv_gemm_tn16_supported(M, 2N, K, 0)
+// says).  See hgv_gemm_tn_gg for the use.
+extern "C" int hgv_gemm_tn16_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda,
+                                int K, int64_t M, float* GW, int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes,
+                                hipStream_t stream) {
+    HGV_REQUIRE(Gb != nullptr && N > 0 && N % 4 == 0, HGV_EINVAL, "gemm_tn16_gg: two gradient matrices of a width that is a multiple of 4");
+    return gemm_tn16_any(false, Ga, ldga, 2 * N, A, lda, K, GW, ldgw, nullptr, 0, 0, nullptr, 0, M, gbias, accumulate, ws, ws_bytes,
+                         stream, Gb, ldgb, N);
 }

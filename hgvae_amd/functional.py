@@ -1219,6 +1219,19 @@ def _gemm_tn_gg(ga, gb, x, out_a=None, out_b=None, cs_a=None, cs_b=None, accumul
         raise _lib.HgvError(f"two-gradient product of {tuple(ga.shape)} and {tuple(gb.shape)} with {tuple(x.shape)}")
     if accumulate and (out_a is None or out_b is None or cs_a is None or cs_b is None):
         raise _lib.HgvError("accumulating weight gradients needs existing output buffers")
+    if out_a is None and out_b is None and cs_a is None and cs_b is None and n % 4 == 0 and _tn16_ok(m, 2 * n, k, 0, ga, gb, x):
+        # fresh outputs: one product on the 16-bit matrix cores, the two results as row blocks of one matrix
+        both = torch.empty(2 * n, k, dtype=torch.float32, device=x.device)
+        sums = torch.empty(2 * n, dtype=torch.float32, device=x.device)
+        ws = _workspace(_lib.load().hgv_gemm_tn16_ws(m, 2 * n, k, 0), x.device, "gemm_tn")
+        ev = _probe.add("tn", (m, 2 * n, k)) if _probe is not None else None
+        if ev:
+            ev[0].record()
+        _lib.call("hgv_gemm_tn16_gg", ga.data_ptr(), ld_of(ga), gb.data_ptr(), ld_of(gb), n, x.data_ptr(), ld_of(x), k, m,
+                  both.data_ptr(), both.stride(0), sums.data_ptr(), 0, ws.data_ptr(), ws.numel(), _lib.stream())
+        if ev:
+            ev[1].record()
+        return both[:n], both[n:], sums[:n], sums[n:]
     wa = torch.empty(n, k, dtype=torch.float32, device=x.device) if out_a is None else out_a
     wb = torch.empty(n, k, dtype=torch.float32, device=x.device) if out_b is None else out_b
     _check_gw(wa, n, k)

@@ -327,6 +327,11 @@ size_t hgv_gemm_tn_gg_ws(int64_t M, int N, int K);
 int hgv_gemm_tn_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda, int K,
                    int64_t M, float* GWa, int64_t ldgwa, float* GWb, int64_t ldgwb, float* gbias_a, float* gbias_b,
                    int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* The same on the bf16 matrix cores, as one product: GW[2N, K] (+)= [Ga | Gb]^T A, gbias[2N] (+)= column sums of Ga, then
+ * of Gb; N a multiple of 4, shapes as hgv_gemm_tn16_supported(M, 2N, K, 0) says, workspace hgv_gemm_tn16_ws(M, 2N, K, 0). */
+int hgv_gemm_tn16_gg(const float* Ga, int64_t ldga, const float* Gb, int64_t ldgb, int N, const float* A, int64_t lda, int K,
+                     int64_t M, float* GW, int64_t ldgw, float* gbias, int accumulate, void* ws, size_t ws_bytes,
+                     hgv_stream_t stream);
 
 /* ---- the same projections on the bf16 matrix cores at fp32 accuracy ("bf16x6": every operand split into three
  *      bf16 pieces, six piece products per fp32 product, fp32 accumulation) -------------------------------------

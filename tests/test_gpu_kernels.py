@@ -742,11 +742,14 @@ def test_two_gradient_matrices_against_one_operand(m, n, k):
     Fn._gemm_tn_gg(ga, gb, x, both[:n], both[n:], sums[0], sums[1], accumulate=True)
     assert float((both.double() - 2 * ref).abs().max()) <= 2 * tol
     assert float((sums.double() - 2 * refs).abs().max()) <= 2 * tols
+    # fresh outputs: where the shape allows, one product on the 16-bit matrix cores (hgv_gemm_tn16_gg)
     wa, wb, ca, cb = Fn._gemm_tn_gg(ga, gb, x)
+    assert float((torch.cat([wa, wb]).double() - ref).abs().max()) <= 1.5 * tol         # 1e-8 of the sum of |terms| at 1.28 M rows
+    assert float((torch.stack([ca, cb]).double() - refs).abs().max()) <= 1.5 * tols
     sep_a, csa = Fn._gemm_tn(ga, x, True)
     sep_b, csb = Fn._gemm_tn(gb, x, True)
     for got, want in ((wa, sep_a), (wb, sep_b), (ca, csa), (cb, csb)):
-        assert float((got.double() - want.double()).abs().max()) <= tol
+        assert float((got.double() - want.double()).abs().max()) <= 2.5 * tol
 
 
 def _scaled_cases():
