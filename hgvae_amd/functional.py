@@ -590,13 +590,17 @@ def bn_level_pair(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: floa
     return bn_act_pair(y, bn, relu, p)
 
 
-def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False, act_ok: bool = False):
+def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False, act_ok: bool = False,
+             rows: Optional[int] = None):
     """One level: ``make_y()`` -> relu? -> Dropout(p) -> BatchNorm1d.  ``make_y`` builds the pre-activation (a fresh
     matrix that nothing else reads); the result is a tensor, or inside :func:`deferred_levels` a :class:`Deferred`
     (a pair of either with ``fork``).  ``act_ok``: ``make_y`` is exactly one projection operator of this module (SAGEConv,
-    dual / concatenated linear) and nothing else, so its product may store relu -> dropout itself."""
+    dual / concatenated linear) and nothing else, so its product may store relu -> dropout itself.  ``rows``: the row count
+    of the level when the caller knows it (lets small batches skip the set-up)."""
     global _act_request, _act_done
-    want = _defer and training and torch.is_grad_enabled() and p >= DEFER_MIN_P
+    want = _defer and training and p >= DEFER_MIN_P and (rows is None or rows >= max(2, DEFER_MIN_ROWS)) and torch.is_grad_enabled()
+    if not want:                       # small batches and evaluation: the fused epilogue, nothing to set up
+        return bn_act(plain(make_y()), bn, relu, p, training, fork=fork)
     _act_done = None
     _act_request = (relu, p) if (want and act_ok and _nt_act) else None
     global _act_ready

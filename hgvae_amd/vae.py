@@ -79,7 +79,8 @@ class _VAEBase(nn.Module):
     def _sage_level(self, seq, x, g, fork: bool = False):
         conv, drop, bn = seq[0], seq[1], seq[2]
         # a SAGEConv is one projection operator (its product may store relu -> dropout itself); attention layers are not
-        return Fn.bn_level(lambda: conv(x, g), bn, True, drop.p, self.training, fork=fork, act_ok=type(conv) is SAGEConv)
+        return Fn.bn_level(lambda: conv(x, g), bn, True, drop.p, self.training, fork=fork, act_ok=type(conv) is SAGEConv,
+                           rows=x.size(0))
 
     def _linear_level(self, xa, xb, lin, dropout, bn, relu: bool):
         """Decoder level: Linear over xa (or over [xa | xb]) -> (relu) -> dropout -> batch norm."""
@@ -87,7 +88,7 @@ class _VAEBase(nn.Module):
             make = lambda: Fn.dual_linear(xa, lin.weight, None, None, lin.bias)       # noqa: E731
         else:
             make = lambda: Fn.concat_linear(xa, xb, lin.weight, lin.bias)             # noqa: E731
-        return Fn.bn_level(make, bn, relu, dropout.p if dropout is not None else 0.0, self.training, act_ok=True)
+        return Fn.bn_level(make, bn, relu, dropout.p if dropout is not None else 0.0, self.training, act_ok=True, rows=xa.size(0))
 
     def reparameterize(self, mean, log_std):
         ml = join_head(mean, log_std)
