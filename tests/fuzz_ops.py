@@ -520,6 +520,22 @@ def run(cases: int, seed: int, verbose: bool = False):
     return None, worst
 
 
+def run_models(cases: int, seed: int):
+    """Whole-step cases only (fuzz_model): (failure message or None, worst errors, cases whose bar was widened)."""
+    rng = random.Random(seed)
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    worst, widened = {}, 0
+    for i in range(cases):
+        name, errs, tol = fuzz_model(rng, gen)
+        w = errs.pop("_widening", None)
+        widened += 1 if (w is not None and w > 1.0) else 0
+        for k, v in errs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+            if not v <= tol:
+                return f"case {i} (seed {seed}): {name}: {k} = {v:.3e} (> {tol:g})", worst, widened
+    return None, worst, widened
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
