@@ -220,8 +220,10 @@ constexpr int PACE_WGS = 256, PACE_WAVES = 16, PACE_SPINS = 512, PACE_AHEAD = 2;
 constexpr int64_t PACE_MIN_BYTES = (int64_t)256 << 20;
 __device__ int pace_ctr_h[HGV_PACE_SLOTS * 2 * PACE_WGS * PACE_WAVES];
 
+// Waves per workgroup of the 7-9-tile kernels.  Measured on whole 256-graph train steps (same box, ms per step):
+// 6: 30.29, 8: 29.90, 10: 30.50, 12: 30.48, 16: 33.2; the depth of the load ring (3-6) changes nothing at any of them.
 #ifndef NTH_WAVES_WIDE
-#define NTH_WAVES_WIDE 12
+#define NTH_WAVES_WIDE 8
 #endif
 #ifndef NTH_RING_WIDE
 #define NTH_RING_WIDE 4
