@@ -100,7 +100,7 @@ SIGNATURES = {
     "hgv_gemm_nt16h_gated": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hgv_gemm_nt16h_act_supported": (C.c_int, [_i32, _i32, _i32]),
     "hgv_gemm_nt16h_act": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp]),
-    "hgv_gemm_nt16h_act_parts": (C.c_int, [_i64]),
+    "hgv_gemm_nt16h_act_parts": (C.c_int, [_i64, _i32, _i32, _i32]),
     "hgv_gemm_nt16h_act_stats": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp,
                                            _vp]),
     "hgv_bn_stats_merge": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

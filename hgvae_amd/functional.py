@@ -1009,7 +1009,7 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> 
                   bits.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)))
         partial = None
         if _nt_stats:                  # the product also leaves the column statistics of what it stores
-            nparts = _lib.load().hgv_gemm_nt16h_act_parts(m)
+            nparts = _lib.load().hgv_gemm_nt16h_act_parts(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0)
             partial = torch.empty((nparts, 2, ld_of(out)), dtype=torch.float32, device=xa.device)
             _lib.call("hgv_gemm_nt16h_act_stats", *common, partial.data_ptr(), _lib.stream())
         else:

@@ -470,10 +470,10 @@ int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const float* A2, i
 
 /* hgv_gemm_nt16h_act that also leaves the column statistics of what it stored (the batch statistics of the level's
  * BatchNorm1d, gvae/gvae_skipcon.py:107): stat_partial[parts][2][Hp] (Hp = 4 * ceil(N / 4), parts =
- * hgv_gemm_nt16h_act_parts(M)) receives per part p the (mean, M2) over the rows of the 16-row groups p, p + parts, ... ;
+ * hgv_gemm_nt16h_act_parts(M, N, K1, K2)) receives per part p the (mean, M2) over the rows of the 16-row groups p, p + parts, ... ;
  * hgv_bn_stats_merge(partial, parts, 16, M, N, ...) finishes them.  Plain fp32 sums of d and d^2 per part (M2 formed in
  * fp64): meant for levels behind a dropout of rate p >= 0.2, whose zeros bound mean^2 / variance of d by (1 - p) / p. */
-int hgv_gemm_nt16h_act_parts(int64_t M);
+int hgv_gemm_nt16h_act_parts(int64_t M, int N, int K1, int K2);
 int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                              const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits,
                              int64_t ld_bits, int relu, float scale, float* stat_partial, hgv_stream_t stream);

@@ -172,7 +172,8 @@ def test_two_draws_of_one_pre_activation_as_two_deferred_levels(n, h, which):
 @pytest.mark.parametrize("op,relu,n_out", [("sage", True, 138), ("concat", False, 138), ("dual", True, 144), ("dual", False, 129),
                                            ("sage", True, 64), ("concat", True, 160)])
 @pytest.mark.parametrize("in_product_stats", [False, True])
-def test_projection_stores_the_activated_level_itself(op, relu, n_out, in_product_stats, monkeypatch):
+@pytest.mark.parametrize("n", [3001, 40_007])
+def test_projection_stores_the_activated_level_itself(op, relu, n_out, in_product_stats, n, monkeypatch):
     """hgv_dropout_bits + hgv_gemm_nt16h_act + hgv_bn_stats_pre against the projection followed by hgv_bn_stats_act:
     the stored d (signed zeros included), s / t, the running statistics and every gradient are the same bits; widths the
     activated store does not cover take the other path by themselves.  With the column sums taken inside the product
@@ -180,7 +181,7 @@ def test_projection_stores_the_activated_level_itself(op, relu, n_out, in_produc
     from hgvae_amd import functional as Fn
     from hgvae_amd.graph import graph_of
     from hgvae_amd.noise import PhiloxNoise, use_noise
-    n, k = 3001, 138
+    k = 138               # 40 007 rows: long enough for the projections that keep the weights in registers
     gen = torch.Generator(device=dev()).manual_seed(n_out + int(relu))
     ei, nn_, _ = path_batch([n])
     ei = torch.cat([ei, torch.randint(0, n, (2, 4000))], 1).to(dev())

@@ -47,9 +47,18 @@ def main():
         bias = torch.randn(n, device=dev)
         g = new_padded(m, n, dev); g.normal_()
         img = Fn._image(wa, wb if xb is not None else None, False)
+        if os.environ.get("CHECK"):        # error against float64 on the first, the last and 4096 random rows
+            y = nt_call(xa, img, xb, bias, n)
+            idx = torch.cat([torch.arange(0, min(m, 2048), device=dev), torch.randint(0, m, (4096,), device=dev),
+                             torch.arange(max(m - 2048, 0), m, device=dev)])
+            ref = xa[idx].double() @ wa.double().t() + bias.double()
+            if k2:
+                ref = ref + xb[idx].double() @ wb.double().t()
+            err = float((y[idx].double() - ref).abs().max()) / float(ref.abs().max())
+            print(f"  check M={m} K=({k1},{k2}) N={n}: max error / max |ref| = {err:.2e}", flush=True)
         t_nt = 1.0 if os.environ.get("TN_ONLY") else timeit(lambda: nt_call(xa, img, xb, bias, n))
         fl = 2.0 * m * (k1 + (k2 or 0)) * n
-        t_tn = timeit(lambda: Fn._gemm_tn(g, xa, True))
+        t_tn = 1.0 if os.environ.get("NT_ONLY") else timeit(lambda: Fn._gemm_tn(g, xa, True))
         fl_tn = 2.0 * m * n * k1
         print(f"NT[{img.kind}] M={m} K=({k1},{k2}) N={n}: {t_nt:7.1f} us {fl / t_nt / 1e6:6.1f} TF/s | "
               f"TN N={n} K={k1}: {t_tn:7.1f} us {fl_tn / t_tn / 1e6:6.1f} TF/s", flush=True)
