@@ -18,6 +18,7 @@
 // Layout of the image, LDS residency, the two-part launch and its pacing are those of the bf16 kernel.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -141,11 +142,8 @@ __global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
     const size_t piece_elems = (size_t)rows * 32;
     _Float16* img = a.out + (size_t)part * g.chunks * 2 * piece_elems;
     for (int e = lane; e < (r < rows ? g.chunks * 32 : 0); e += 64) {
-        // slot j of piece q (what lane (i, q) of the matrix-core operand holds in element j) is column
-        // 4 q + (j & 3) + 16 (j >> 2) of the chunk: the lane's 16-byte pieces of the chunk's two 64-byte segments
         const int c = e >> 5, kk = e & 31;
-        const int kin = 4 * (kk >> 3) + (kk & 3) + 16 * ((kk >> 2) & 1);
-        const int blk = 4 * c + (kin >> 3), j = kin & 7;
+        const int blk = 4 * c + (kk >> 3), j = kk & 7;
         float x = 0.f;
         if (n < g.N) {
             if (blk < g.nb1) {
@@ -161,7 +159,7 @@ __global__ __launch_bounds__(256) void k_pack16h(const PackHJobs jobs) {
         const _Float16 h = (_Float16)y;
         const _Float16 l = (_Float16)(y - (float)h);
         const int piece = (kk >> 3) ^ ((r & 8) ? 3 : 0);
-        const size_t base = (size_t)c * 2 * piece_elems + (size_t)r * 32 + piece * 8 + (kk & 7);
+        const size_t base = (size_t)c * 2 * piece_elems + (size_t)r * 32 + piece * 8 + j;
         img[base] = h;
         img[base + piece_elems] = l;
     }
@@ -194,26 +192,6 @@ struct NtHArgs {
     // callers use this form from p = 0.2 upwards
     float* stat_partial; int stat_hp;
 };
-
-// Where the two 16-byte pieces that belong to (chunk e >> 2, piece p = e & 3) lie inside a row.  A 32-wide k chunk is two
-// 64-byte segments of the concatenated sources; piece p of segment s holds the concatenation's columns 32 c + 16 s + 4 p
-// ... + 3.  x / y: byte offset of the piece of segment 0 / 1 inside its row, z / w: 1 when it comes from the second
-// source.  Both stay inside the row's leading dimension (columns past K meet zero weights).
-__device__ __forceinline__ int4 nth_tab_entry(const NtHArgs& a, int e) {
-    const GeoH& g = a.g;
-    const int c = e >> 2, p = e & 3;
-    int off[2], src[2];
-#pragma unroll
-    for (int sgm = 0; sgm < 2; ++sgm) {
-        const int blk = 4 * c + 2 * sgm + (p >> 1), half = 4 * (p & 1);
-        int second = 0, col = 0; int64_t ld = a.lda1;
-        if (blk < g.nb1) { col = 8 * blk + half; }
-        else if (blk < g.nb1 + g.nb2) { second = 1; col = 8 * (blk - g.nb1) + half; ld = a.lda2; }
-        off[sgm] = (int)min((int64_t)col, ld - 4) * 4;
-        src[sgm] = second;
-    }
-    return make_int4(off[0], off[1], src[0], src[1]);
-}
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
@@ -248,13 +226,6 @@ __device__ int pace_ctr_h[HGV_PACE_SLOTS * 2 * PACE_WGS * PACE_WAVES];
 // 6: 30.29, 8: 29.90, 10: 30.50, 12: 30.48, 16: 33.2; the depth of the load ring (3-6) changes nothing at any of them.
 #ifndef NTH_WAVES_WIDE
 #define NTH_WAVES_WIDE 8
-#endif
-#ifndef NTH_COALESCE
-#define NTH_COALESCE 0
-#endif
-// Load groups are issued NTH_BURST steps at a time (the ring holds a multiple of it)
-#ifndef NTH_BURST
-#define NTH_BURST 1
 #endif
 #ifndef NTH_RING_WIDE
 #define NTH_RING_WIDE 4
@@ -291,7 +262,7 @@ __device__ __forceinline__ SplitH split8h(const f32x4 (&av)[2], float s) {
     return o;
 }
 
-template <int NT, int RING, int ACT = 0, int BURST = 1>
+template <int NT, int RING, int ACT = 0>
 __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_raw, const int part, const int wg_rank, const int wgs) {
     const GeoH& g = a.g;
     const int t = threadIdx.x, lane = t & 63, i = lane & 15, kq = lane >> 4;
@@ -318,7 +289,14 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
             for (int u = 0; u < CB; ++u)
                 if (e0 + u * (int)blockDim.x < npieces) dst[e0 + u * (int)blockDim.x] = v[u];
         }
-        for (int e = t; e < g.chunks * 4; e += blockDim.x) tab[e] = nth_tab_entry(a, e);
+        for (int e = t; e < g.chunks * 4; e += blockDim.x) {
+            int second = 0, col = 0; int64_t ld = a.lda1;
+            if (e < g.nb1) { col = 8 * e; }
+            else if (e < g.nb1 + g.nb2) { second = 1; col = 8 * (e - g.nb1); ld = a.lda2; }
+            // both 16-byte halves stay inside the row's leading dimension (columns past K meet zero weights)
+            const int c0 = (int)min((int64_t)col, ld - 4), c1 = (int)min((int64_t)col + 4, ld - 4);
+            tab[e] = make_int4(c0 * 4, c1 * 4, second, 0);
+        }
         const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)g.parts * img);
         for (int e = t; e < NT * 16; e += blockDim.x) {
             const int n = t0 * 16 + e;
@@ -364,37 +342,24 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
 
     int64_t ltile = gw, lidx = 0; int lq = 0;
     const char *lp1, *lp2;
-    // Loads: the four lanes of quad q read the 64-byte segments of row q of the tile piece by piece, so every quad of a load
-    // is one contiguous 64 bytes (lanes that follow the operand layout - 16 consecutive lanes = 16 rows - cost the address
-    // path one cache access per lane: it was busy > 90 % of the launch and the kernel 30 % above the streaming kernels);
-    // a lane-index transposition (ds_bpermute, no LDS memory) then hands lane (i, kq) the pieces kq of row i.
-    const int lrow = NTH_COALESCE ? (lane >> 2) : i, lpc = NTH_COALESCE ? (lane & 3) : kq;
-    const int bsrc = (4 * i + kq) * 4;
     auto row_pointers = [&]() __attribute__((always_inline)) {
-        const int64_t row = min(ltile * 16 + lrow, a.M - 1);
+        const int64_t row = min(ltile * 16 + i, a.M - 1);
         lp1 = reinterpret_cast<const char*>(a.A1 + row * a.lda1);
         lp2 = reinterpret_cast<const char*>((a.A2 ? a.A2 : a.A1) + row * (a.A2 ? a.lda2 : a.lda1));
     };
     f32x4 ring[RING][2];
-    int4 e_next = tab[lpc];
+    int4 e_next = tab[kq];
     auto issue = [&](int d) __attribute__((always_inline)) {
         if (pace) pace_gate(d);
         const int4 e = e_next;
-        ring[d][0] = *reinterpret_cast<const f32x4*>((e.z ? lp2 : lp1) + e.x);
-        ring[d][1] = *reinterpret_cast<const f32x4*>((e.w ? lp2 : lp1) + e.y);
+        const char* p = e.z ? lp2 : lp1;
+        ring[d][0] = *reinterpret_cast<const f32x4*>(p + e.x);
+        ring[d][1] = *reinterpret_cast<const f32x4*>(p + e.y);
         if (++lq == steps) {
             lq = 0;
             if (lidx + 1 < my_tiles) { ++lidx; ltile += nw; row_pointers(); }
         }
-        e_next = tab[lq * 4 + lpc];
-    };
-    // ring slot d in the operand layout
-    auto operand = [&](int d, f32x4 (&av)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                av[h][j] = NTH_COALESCE ? __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc, __float_as_int(ring[d][h][j]))) : ring[d][h][j];
+        e_next = tab[lq * 4 + kq];
     };
     // n tiles in groups of GS: the three piece products of a group are issued term by term across its tiles, so
     // MFMAs that depend on each other are GS instructions apart; the next step's operand is split (with the scale
@@ -405,18 +370,6 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     auto compute = [&](const SplitH& cur, const f32x4 (&av_next)[2], int c, float s_next) __attribute__((always_inline)) {
         const unsigned char* base = lds_raw + (size_t)c * 2 * rows * 64;
         SplitH nxt;
-#ifdef NTH_ABLATE      // lab builds.  1: loads, scale, split and stores only; 2: no split either
-#if NTH_ABLATE == 1
-        nxt = split8h(av_next, s_next);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n][0] += (float)cur.h[n & 7] + (float)cur.l[n & 7];
-#else
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { nxt.h[j] = (_Float16)0.f; nxt.l[j] = (_Float16)0.f; }
-        acc[0] += av_next[0] * s_next; acc[1 % NT] += av_next[1];
-#endif
-        return nxt;
-#endif
         int el = 0;          // compile-time after unrolling: elements of the next operand split so far
 #pragma unroll
         for (int n0 = 0; n0 < NT; n0 += GS) {
@@ -468,8 +421,7 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     SplitH cur;
     float s_cur = 1.f, inv_cur = 1.f;          // scale of the lane's row in the tile being accumulated
     if (my_tiles > 0) {
-        f32x4 av0[2];
-        operand(0, av0);
+        const f32x4 av0[2] = {ring[0][0], ring[0][1]};
         s_cur = scale_for(row_amax(av0), inv_cur);
         cur = split8h(av0, s_cur);
 #pragma unroll
@@ -478,22 +430,13 @@ __device__ __forceinline__ void nth_body(const NtHArgs& a, unsigned char* lds_ra
     for (int64_t u0 = 0; u0 < S; u0 += RING) {
 #pragma unroll
         for (int d = 0; d < RING; ++d) {
-            // slot d has been split already; with BURST > 1 the refills wait until BURST slots are free
-            if ((d + 1) % BURST == 0) {
-#pragma unroll
-                for (int b = d + 1 - BURST; b <= d; ++b) issue(b);
-            }
+            issue(d);
             if (u0 + d < S) {
-                f32x4 av_next[2];
-                operand((d + 1) % RING, av_next);
+                const f32x4 av_next[2] = {ring[(d + 1) % RING][0], ring[(d + 1) % RING][1]};
                 // scale of the next step: a new tile starts from its first chunk; inside a tile the scale only ever
                 // goes down, when the chunk would leave the fp16 range with the current one
                 const bool fresh = cq + 1 == steps;
-#if defined(NTH_ABLATE) && NTH_ABLATE >= 3
-                const float amax = 1.f;
-#else
                 const float amax = row_amax(av_next);
-#endif
                 const bool grow = amax * s_cur > 32768.f;
                 float inv_t;
                 const float s_t = scale_for(amax, inv_t);
@@ -606,8 +549,7 @@ template <int NT, int ACT = 0>
 __global__ __launch_bounds__(64 * nth_waves<NT>()) void k_gemm_nt16h(const NtHArgs a, const int part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
-    static_assert(nth_ring<NT>() % (NT > 6 ? NTH_BURST : 1) == 0, "the ring holds whole bursts");
-    nth_body<NT, nth_ring<NT>(), ACT, (NT > 6 ? NTH_BURST : 1)>(a, lds_raw, part, blockIdx.x, gridDim.x);
+    nth_body<NT, nth_ring<NT>(), ACT>(a, lds_raw, part, blockIdx.x, gridDim.x);
 }
 
 template <int NT0, int NT1>
@@ -633,7 +575,13 @@ __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
     int4* tab = reinterpret_cast<int4*>(lds_raw + 2 * CHUNK_BYTES);
     float* bias_s = reinterpret_cast<float*>(lds_raw + 2 * CHUNK_BYTES + (size_t)g.chunks * 64);
     float* invw_s = bias_s + ROWS;
-    for (int e = t; e < g.chunks * 4; e += 768) tab[e] = nth_tab_entry(a, e);
+    for (int e = t; e < g.chunks * 4; e += 768) {
+        int second = 0, col = 0; int64_t ld = a.lda1;
+        if (e < g.nb1) { col = 8 * e; }
+        else if (e < g.nb1 + g.nb2) { second = 1; col = 8 * (e - g.nb1); ld = a.lda2; }
+        const int c0 = (int)min((int64_t)col, ld - 4), c1 = (int)min((int64_t)col + 4, ld - 4);
+        tab[e] = make_int4(c0 * 4, c1 * 4, second, 0);
+    }
     {
         const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + part_bytes_h(g.rows, g.chunks));
         for (int e = t; e < ROWS; e += 768) {
@@ -665,10 +613,9 @@ __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
     auto a_load = [&](int64_t rb, int c) __attribute__((always_inline)) {
         const int64_t row = min((rb * 12 + wib) * 16 + i, a.M - 1);
         const int4 e = tab[c * 4 + kq];
-        const char* p1 = reinterpret_cast<const char*>(a.A1 + row * a.lda1);
-        const char* p2 = a.A2 ? reinterpret_cast<const char*>(a.A2 + row * a.lda2) : p1;
-        a_nx[0] = *reinterpret_cast<const f32x4*>((e.z ? p2 : p1) + e.x);
-        a_nx[1] = *reinterpret_cast<const f32x4*>((e.w ? p2 : p1) + e.y);
+        const char* p = e.z ? reinterpret_cast<const char*>(a.A2 + row * a.lda2) : reinterpret_cast<const char*>(a.A1 + row * a.lda1);
+        a_nx[0] = *reinterpret_cast<const f32x4*>(p + e.x);
+        a_nx[1] = *reinterpret_cast<const f32x4*>(p + e.y);
     };
     int buf = 0;
     if ((int64_t)blockIdx.x < nblocks) a_load(blockIdx.x, 0);
@@ -763,7 +710,7 @@ __global__ __launch_bounds__(768) void k_gemm_nt16hs(const NtHArgs a) {
 // scale of the streaming kernels: same error bound, not the same bits.
 constexpr int NTR_LDC = 148;           // floats per staged output row: 16-byte writes of 16 rows hit distinct banks
 constexpr int NTR_R = 16;              // rows per block
-constexpr int NTR_MOVERS = 256;        // four mover waves behind the nine multiplier waves: 16 lanes per row of the block
+constexpr int NTR_MOVERS = 256;        // four mover waves behind the (up to nine) multiplier waves: 16 lanes per row of the block
 constexpr int NTR_THREADS = 576 + NTR_MOVERS;
 constexpr int NTR_EPT = 3;             // float4 per mover thread, source and block: lanes 0 ... 11 of a row take f, f + 12, f + 24
 #ifndef NTR_SLOTS
@@ -776,7 +723,7 @@ constexpr int NTR_EPT = 3;             // float4 per mover thread, source and bl
 
 __host__ __device__ constexpr size_t ntr_astage_bytes(int chunks) { return (size_t)chunks * 2 * NTR_R * 64; }
 __host__ __device__ constexpr size_t ntr_lds_bytes(int chunks) {
-    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4;
+    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 8 * 4;
 }
 
 template <class F, int... Is>
@@ -795,25 +742,30 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
     unsigned char* astage = lds_raw;
     float* cstage = reinterpret_cast<float*>(lds_raw + 2 * ASTAGE);
     float* rowinv = cstage + 2 * R * NTR_LDC;                        // [2][R]: inverse scale of every row of a staged block
+    // ACT: keep bits of the rows of the last four blocks, [4][R][8 words].  The movers load them with the rows (their waits on
+    // loads are counted ones) and hand them over here: a load inside the multipliers' loop made every interval wait for the
+    // completion of the store in front of it
+    uint32_t* kbits = reinterpret_cast<uint32_t*>(rowinv + 2 * R);
     // columns the sources do not reach stay zero in both stage buffers for the whole launch (their weights are zero,
     // but 0 x garbage is not)
-    for (int e = t; e < (int)(2 * ASTAGE / 16); e += NTR_THREADS) reinterpret_cast<f32x4*>(astage)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = t; e < (int)(2 * ASTAGE / 16); e += (int)blockDim.x) reinterpret_cast<f32x4*>(astage)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int64_t nblocks = (a.M + R - 1) / R;
     const int64_t G = gridDim.x;
     const int64_t mine = (int64_t)blockIdx.x < nblocks ? (nblocks - 1 - blockIdx.x) / G + 1 : 0;
     auto block_of = [&](int64_t it) __attribute__((always_inline)) { return (int64_t)blockIdx.x + it * G; };
-    const int nc4 = (int)(min(a.ldc, (int64_t)144) / 4);
+    const int ntiles = g.tiles;                                      // multiplier waves; the four mover waves follow them
+    const int nc4 = (int)(min(a.ldc, (int64_t)16 * ntiles) / 4);
     constexpr auto slots = std::make_integer_sequence<int, SLOTS>{};
     // intervals 0 ... mine, rounded up to one + a multiple of SLOTS (the slot of a block is a compile-time index): past the
     // end every step repeats the workgroup's last block - same loads, same staged bytes, same products, same stores
-    // (ACT = 2: one more round, in which the multipliers pick up what the last store left for them)
-    const int64_t intervals = 1 + (mine + SLOTS - 1) / SLOTS * SLOTS + (ACT == 2 ? SLOTS : 0);
+    const int64_t intervals = 1 + (mine + SLOTS - 1) / SLOTS * SLOTS;
+    const int64_t last = mine > 0 ? mine - 1 : 0;
 
     // Every wave passes the same barriers: two in front of the intervals, then one per interval it = 0 ... mine.  Interval it
-    // holds the products of block it (multiplier waves) next to, for the mover waves, the scale + split + stage of block it + 1,
-    // the stores of block it - 1 and the loads of block it + SLOTS.
-    if (w < 9) {
+    // holds, for the multiplier waves, the stores of block it - 1 and the products of block it, next to, for the mover waves,
+    // the loads of block it + SLOTS and the scale + split + stage of block it + 1.
+    if (w < ntiles) {
         // ---- multiplier wave w: output columns 16 w ... 16 w + 15.  Lane (i, kq) holds image row 16 w + i, piece kq of every
         // chunk (a last tile stored without its dead rows repeats the last stored row; those outputs meet an inverse scale of zero)
         f16x8 wh[CHUNKS], wl[CHUNKS];
@@ -837,20 +789,43 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
                 bias4[r] = (a.bias && n < g.N) ? a.bias[n] : 0.f;
             }
         }
+        // store element of this thread: float4 e = t of the block's R x nc4 float4 of output (64 per multiplier wave; threads
+        // past the end repeat the last one), rows past the end of the matrix repeat its last row - same values, same address
+        const int se = min(t, R * nc4 - 1), srow = se / nc4, scol = 4 * (se % nc4);
+        const int soff = srow * (int)a.ldc + scol;
+        auto rows_over = [&](int64_t r0) __attribute__((always_inline)) {
+            const int d = (int)max(r0 - (a.M - 1), (int64_t)-R);        // uniform: - R ... 0
+            return max(d + srow, 0);
+        };
+        f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};        // ACT = 2: sums of what this thread stored
+        const int dropped = a.act_relu ? 0 : (int)0x80000000u;
         __syncthreads();
         __syncthreads();
         const int qoff = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
-        // ACT = 2: the movers leave what they stored of block it - 2 (zeros for rows that do not count) where this lane wrote its
-        // products of that block, and the lane adds it up before it writes the next ones there: sums by position, in registers
-        f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int64_t it = 0; it < intervals; ++it) {
+            if (it >= 1) {          // block it - 1 (the workgroup's last one again past the end): staged products -> rows of C
+                const int64_t r0 = block_of(min(it - 1, last)) * R;
+                const int over = rows_over(r0);
+                f32x4 o = *reinterpret_cast<const f32x4*>(cstage + ((it - 1) & 1) * R * NTR_LDC + srow * NTR_LDC + scol);
+                if (ACT) {
+                    const uint32_t nib = kbits[(((it - 1) & 3) * R + srow) * 8 + (scol >> 5)] >> (scol & 31);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {          // keep bit -> all-ones / zero mask (v_bfe_i32), then a bit select (v_bfi_b32)
+                        const int keep = __builtin_amdgcn_sbfe(nib, r, 1);
+                        o[r] = __int_as_float((__float_as_int(o[r]) & keep) | (dropped & ~keep));
+                    }
+                }
+                *reinterpret_cast<f32x4*>(a.C + r0 * a.ldc + (unsigned)(soff - over * (int)a.ldc)) = o;
+                if (ACT == 2) {
+                    const bool counts = it - 1 <= last && over == 0 && t < R * nc4;          // the first and only time this element is stored
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = counts ? o[r] : 0.f; st1[r] += d; st2[r] += d * d; }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // the store leaves before the products start
             {
                 const unsigned char* q = astage + (it & 1) * ASTAGE + qoff;
                 float* dst = cstage + (it & 1) * R * NTR_LDC;
-                if (ACT == 2 && it >= 2) {
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(dst + i * NTR_LDC + 16 * w + 4 * kq);
-                    st1 += d; st2 += d * d;
-                }
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
                 f16x8 ah[2], al[2];
                 ah[0] = *reinterpret_cast<const f16x8*>(q);
@@ -862,13 +837,9 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
                         ah[(c + 1) & 1] = *reinterpret_cast<const f16x8*>(q + (c + 1) * 2 * R * 64);
                         al[(c + 1) & 1] = *reinterpret_cast<const f16x8*>(q + (c + 1) * 2 * R * 64 + R * 64);
                     }
-#if defined(NTR_ABLATE) && NTR_ABLATE == 1          // lab: no products
-                    acc[0] += (float)ah[c & 1][0] + (float)al[c & 1][0] + (float)wl[c][0] + (float)wh[c][0];
-#else
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], ah[c & 1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], al[c & 1], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], ah[c & 1], acc, 0, 0, 0);
-#endif
                 }
                 f32x4 o;
 #pragma unroll
@@ -885,29 +856,15 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
             }
             __syncthreads();
         }
-        if (ACT == 2) {
-            // the 16 lanes that share kq hold the 16 rows of the blocks: their sums added in double, lane i = 0 writes the four
-            // columns 16 w + 4 kq ... + 3.  Workgroup b of G holds the 16-row groups b, b + G, ...
-            const int64_t part = blockIdx.x, ntiles = nblocks;
-            const int64_t groups = part < ntiles ? (ntiles - 1 - part) / G + 1 : 0;
-            const double nrows = (double)(groups * 16 - ((groups > 0 && (ntiles - 1) % G == part) ? ntiles * 16 - a.M : 0));
-            float* dst = a.stat_partial + part * 2 * a.stat_hp;
+        if (ACT == 2) {          // the stage buffers are dead: this thread's sums, for the addition over the rows below
+            float* red = reinterpret_cast<float*>(astage);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double s1 = (double)st1[r], s2 = (double)st2[r];
-#pragma unroll
-                for (int sh = 8; sh >= 1; sh >>= 1) { s1 += __shfl_xor(s1, sh); s2 += __shfl_xor(s2, sh); }
-                const int col = 16 * w + 4 * kq + r;
-                if (i == 0 && col < a.stat_hp) {
-                    dst[col] = groups > 0 ? (float)(s1 / nrows) : 0.f;
-                    dst[a.stat_hp + col] = groups > 0 ? (float)(s2 - s1 * s1 / nrows) : 0.f;
-                }
-            }
+            for (int r = 0; r < 4; ++r) { red[t * 8 + r] = st1[r]; red[t * 8 + 4 + r] = st2[r]; }
         }
     } else {
         // ---- mover thread (row mr of the block, lane mj of the row's 16): float4 f = min(mj, 11) + 12 u (u = 0, 1, 2) of the row,
-        // the last one repeated where the row is shorter - same loads, same staged bytes, same stores; lanes 12 ... 15 repeat lane 11
-        const int tl = t - 9 * 64, mr = tl >> 4, mj = min(tl & 15, 11);
+        // the last one repeated where the row is shorter - same loads, same staged bytes; lanes 12 ... 15 repeat lane 11
+        const int tl = t - ntiles * 64, mr = tl >> 4, mj = min(tl & 15, 11);
         int eoff[NSRC][EPT], ewr[NSRC][EPT];          // element offset (floats) from the block's first row; byte offset of its h halves in a stage buffer
 #pragma unroll
         for (int sidx = 0; sidx < NSRC; ++sidx) {
@@ -917,25 +874,23 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
                 const int f = min(mj + 12 * u, nf4 - 1);
                 eoff[sidx][u] = mr * (int)(sidx ? a.lda2 : a.lda1) + 4 * f;
                 const int kc = (sidx ? 8 * g.nb1 : 0) + 4 * f;            // column of the concatenation
-                const int c = kc >> 5, c4 = (kc >> 2) & 7;
-                ewr[sidx][u] = ((c * 2) * R + mr) * 64 + (((c4 & 3) ^ ((mr & 8) ? 3 : 0)) * 16) + (c4 >> 2) * 8;
+                const int c = kc >> 5, c4 = (kc >> 2) & 7;          // piece c4 >> 1 of the chunk (its columns 8 q ... 8 q + 7), half c4 & 1
+                ewr[sidx][u] = ((c * 2) * R + mr) * 64 + (((c4 >> 1) ^ ((mr & 8) ? 3 : 0)) * 16) + (c4 & 1) * 8;
             }
         }
-        int toff[EPT], tcol[EPT]; bool tok[EPT];      // store elements: float4 of the block's R x nc4 float4 of output
-#pragma unroll
-        for (int u = 0; u < EPT; ++u) {
-            const int f = min(mj + 12 * u, nc4 - 1);
-            tok[u] = (tl & 15) < 12 && mj + 12 * u < nc4;
-            tcol[u] = 4 * f;
-            toff[u] = mr * (int)a.ldc + 4 * f;
-        }
         f32x4 raw[SLOTS][NSRC][EPT];
-        const int64_t last = mine > 0 ? mine - 1 : 0;
-        // rows past the end of the matrix (last block of the launch) repeat its last row: loads, staged bytes and stored values
+        uint32_t kb[SLOTS];                           // ACT: word min(lane of the row, 7) of the row's keep bits
+        const int kword = min(min(tl & 15, 7), (int)a.act_ldb - 1);
+        // rows past the end of the matrix (last block of the launch) repeat its last row.  rows_over: rows of this thread past
+        // the last row when its block starts at r0 (scalar part first: two VALU instructions)
+        auto rows_over = [&](int64_t r0) __attribute__((always_inline)) {
+            const int d = (int)max(r0 - (a.M - 1), (int64_t)-R);        // uniform: - R ... 0
+            return max(d + mr, 0);
+        };
         auto gload = [&](auto slot, int64_t it) __attribute__((always_inline)) {
             constexpr int S = decltype(slot)::value;
             const int64_t r0 = block_of(min(it, last)) * R;
-            const int over = (int)(max(r0 + mr, a.M - 1) - (a.M - 1));
+            const int over = rows_over(r0);
 #pragma unroll
             for (int sidx = 0; sidx < NSRC; ++sidx) {
                 const float* base = sidx ? a.A2 + r0 * a.lda2 : a.A1 + r0 * a.lda1;          // uniform base + 32-bit lane offset
@@ -943,11 +898,19 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) raw[S][sidx][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoff[sidx][u] - back));
             }
+            if (ACT) kb[S] = (a.act_bits + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
         };
         // scale of the row from its largest entry (the row's 16 lanes hold all of it), split, stage; the inverse scale for the multipliers
         auto stage = [&](auto slot, int64_t it) __attribute__((always_inline)) {
             constexpr int S = decltype(slot)::value;
             unsigned char* dst = astage + (it & 1) * ASTAGE;
+            // the slot's values exist from here on: without this the compiler starts on the row maxima one interval early, right
+            // behind the loads, and waits for them there
+#pragma unroll
+            for (int sidx = 0; sidx < NSRC; ++sidx)
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(raw[S][sidx][u]));
+            if (ACT) asm volatile("" : "+v"(kb[S]));
             float m = 0.f;
 #pragma unroll
             for (int sidx = 0; sidx < NSRC; ++sidx)
@@ -963,6 +926,7 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
             float inv;
             const float sc = scale_for(m, inv);
             rowinv[(it & 1) * R + mr] = inv;
+            if (ACT) kbits[((it & 3) * R + mr) * 8 + min(tl & 15, 7)] = kb[S];
             // elements two at a time: the split of eight values compiles to packed multiplies / conversions
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             constexpr int NE = NSRC * EPT;
@@ -980,66 +944,45 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
                 __builtin_amdgcn_sched_barrier(0);      // pair by pair: interleaved, the temporaries of all pairs do not fit next to the slots
             }
         };
-        // keep bits of the block stored in the NEXT interval: loaded in front of this interval's row loads, so the wait for them
-        // is a counted one as well
-        uint32_t kbits[EPT], kcur[EPT];
-        auto bits_load = [&](int64_t it) __attribute__((always_inline)) {
-            const int64_t r0 = block_of(min(it, last)) * R;
-            const int over = (int)(max(r0 + mr, a.M - 1) - (a.M - 1));
-            const uint32_t* bbase = a.act_bits + (r0 + mr - over) * a.act_ldb;
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) kbits[u] = bbase[tcol[u] >> 5];
-        };
-        auto store = [&](int64_t it) __attribute__((always_inline)) {
-            float* src = cstage + (it & 1) * R * NTR_LDC + mr * NTR_LDC;
-            const int64_t r0 = block_of(min(it, last)) * R;
-            const int over = (int)(max(r0 + mr, a.M - 1) - (a.M - 1));
-            float* cbase = a.C + r0 * a.ldc;
-            const bool count = it <= last && over == 0;          // the first time this row is stored
-            const float dropped = a.act_relu ? 0.f : -0.f;
-            const int back = over * (int)a.ldc;
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                f32x4 o = *reinterpret_cast<const f32x4*>(src + tcol[u]);
-                if (ACT) {
-                    const uint32_t nib = kcur[u] >> (tcol[u] & 31);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = ((nib >> r) & 1u) ? o[r] : dropped;
-                }
-                *reinterpret_cast<f32x4*>(cbase + (unsigned)(toff[u] - back)) = o;
-                if (ACT == 2) {
-                    f32x4 d;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) d[r] = count ? o[r] : 0.f;
-                    *reinterpret_cast<f32x4*>(src + tcol[u]) = d;          // for the multiplier that owns the position (repeats write the same)
-                }
-            }
-        };
-
         ntr_for([&](auto k) __attribute__((always_inline)) { gload(k, decltype(k)::value); }, slots);
         __syncthreads();
         stage(std::integral_constant<int, 0>{}, 0);
         __syncthreads();
         // The interval has no branches, so the waits on the loads stay counted (behind a branch every wait becomes vmcnt(0):
         // nothing would stay in flight across a barrier).  Slot k = it mod SLOTS held block it, staged one interval ago.
-        auto interval = [&](auto first, auto k, int64_t it) __attribute__((always_inline)) {
+        auto interval = [&](auto k, int64_t it) __attribute__((always_inline)) {
             constexpr int K = decltype(k)::value;
-            if (ACT) {
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) kcur[u] = kbits[u];          // loaded one interval ago, for the block stored now
-                bits_load(it);
-            }
             gload(k, it + SLOTS);
             __builtin_amdgcn_sched_barrier(0);          // the loads leave first
             stage(std::integral_constant<int, (K + 1) % SLOTS>{}, it + 1);
-            if (!decltype(first)::value) store(it - 1);
             __builtin_amdgcn_sched_barrier(0);          // nothing of the next interval (its stage step waits for loads) moves up
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
         };
-        interval(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+        interval(std::integral_constant<int, 0>{}, 0);
         for (int64_t it = 1; it < intervals; it += SLOTS)
-            ntr_for([&](auto k) __attribute__((always_inline)) { interval(std::false_type{}, std::integral_constant<int, (decltype(k)::value + 1) % SLOTS>{}, it + decltype(k)::value); }, slots);
+            ntr_for([&](auto k) __attribute__((always_inline)) { interval(std::integral_constant<int, (decltype(k)::value + 1) % SLOTS>{}, it + decltype(k)::value); }, slots);
+    }
+    if (ACT == 2) {
+        // per column: the sums of the 16 threads that stored it, added in row order; workgroup b of G holds the 16-row groups b, b + G, ...
+        __syncthreads();
+        const float* red = reinterpret_cast<const float*>(astage);
+        const int ncol = 4 * nc4;
+        if (t < ncol) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int r = 0; r < R; ++r) {
+                s1 += (double)red[((t >> 2) + nc4 * r) * 8 + (t & 3)];
+                s2 += (double)red[((t >> 2) + nc4 * r) * 8 + 4 + (t & 3)];
+            }
+            const int64_t part = blockIdx.x;
+            const int64_t groups = part < nblocks ? (nblocks - 1 - part) / G + 1 : 0;
+            const double nrows = (double)(groups * 16 - ((groups > 0 && (nblocks - 1) % G == part) ? nblocks * 16 - a.M : 0));
+            float* dst = a.stat_partial + part * 2 * a.stat_hp;
+            if (t < a.stat_hp) {
+                dst[t] = groups > 0 ? (float)(s1 / nrows) : 0.f;
+                dst[a.stat_hp + t] = groups > 0 ? (float)(s2 - s1 * s1 / nrows) : 0.f;
+            }
+        }
     }
 }
 
@@ -1112,11 +1055,14 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
 #ifndef NTR_ENABLE
 #define NTR_ENABLE 1
 #endif
-// the register-weight kernel covers one-part images of nine column tiles over 5 (one source) or 9 (two sources) k chunks,
-// sources of at most 144 columns, from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards
-bool ntr_usable(const GeoH& g, int64_t M, bool two) {
-    if (!NTR_ENABLE || g.stream || g.parts != 1 || g.tiles != 9 || g.K1 > 144 || g.K2 > 144) return false;
-    if (!((g.chunks == 5 && !two) || (g.chunks == 9 && two))) return false;
+// the register-weight kernel covers one-part images of three to nine column tiles over up to nine k chunks, sources of at most
+// 144 columns, from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards; the activated stores are built for the two
+// shapes of the level tails (138 -> 129...144 and 138 + 138 -> 129...144)
+bool ntr_usable(const GeoH& g, int64_t M, bool two, bool act) {
+    // (one or two column tiles: two multiplier waves do not keep four movers busy - 138 -> 28 takes 215 us here, 206 streaming)
+    if (!NTR_ENABLE || g.stream || g.parts != 1 || g.tiles < 3 || g.tiles > 9 || g.chunks > 9 || g.K1 > 144 || g.K2 > 144) return false;
+    if (two ? g.chunks < 2 : g.chunks > 5) return false;
+    if (act && !((g.chunks == 5 && !two) || (g.chunks == 9 && two))) return false;
     return hgv_cdiv(M, NTR_R) >= (int64_t)NTR_MIN_BLOCKS_PER_WG * cu_count_h();
 }
 #ifndef NTR_WGS_LIGHT
@@ -1133,17 +1079,35 @@ int launch_ntr_k(const NtHArgs& a, hipStream_t st) {
     auto kern = k_gemm_nt16r<CHUNKS, NSRC, ACT, NTR_SLOTS>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntr_grid(a.M, CHUNKS <= 5 && ACT == 0)), dim3(NTR_THREADS), ntr_lds_bytes(CHUNKS), st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntr_grid(a.M, CHUNKS <= 5 && ACT == 0)), dim3((unsigned)(64 * a.g.tiles + NTR_MOVERS)),
+                       ntr_lds_bytes(CHUNKS), st, a);
     return HGV_OK;
 }
-template <int ACT>
-int launch_ntr_act(const NtHArgs& a, hipStream_t st) {
-    return a.A2 ? launch_ntr_k<9, 2, ACT>(a, st) : launch_ntr_k<5, 1, ACT>(a, st);
-}
 int launch_ntr(const NtHArgs& a, hipStream_t st) {
-    if (a.act_bits && a.stat_partial) return launch_ntr_act<2>(a, st);
-    if (a.act_bits) return launch_ntr_act<1>(a, st);
-    return launch_ntr_act<0>(a, st);
+    if (a.act_bits) {
+        const bool stats = a.stat_partial != nullptr;
+        if (a.A2) return stats ? launch_ntr_k<9, 2, 2>(a, st) : launch_ntr_k<9, 2, 1>(a, st);
+        return stats ? launch_ntr_k<5, 1, 2>(a, st) : launch_ntr_k<5, 1, 1>(a, st);
+    }
+    if (a.A2) {
+        switch (a.g.chunks) {
+            case 2: return launch_ntr_k<2, 2, 0>(a, st);
+            case 3: return launch_ntr_k<3, 2, 0>(a, st);
+            case 4: return launch_ntr_k<4, 2, 0>(a, st);
+            case 5: return launch_ntr_k<5, 2, 0>(a, st);
+            case 6: return launch_ntr_k<6, 2, 0>(a, st);
+            case 7: return launch_ntr_k<7, 2, 0>(a, st);
+            case 8: return launch_ntr_k<8, 2, 0>(a, st);
+            default: return launch_ntr_k<9, 2, 0>(a, st);
+        }
+    }
+    switch (a.g.chunks) {
+        case 1: return launch_ntr_k<1, 1, 0>(a, st);
+        case 2: return launch_ntr_k<2, 1, 0>(a, st);
+        case 3: return launch_ntr_k<3, 1, 0>(a, st);
+        case 4: return launch_ntr_k<4, 1, 0>(a, st);
+        default: return launch_ntr_k<5, 1, 0>(a, st);
+    }
 }
 
 template <int NT>
@@ -1309,7 +1273,7 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     if (act_bits) HGV_REQUIRE(!a.g.stream && a.g.parts == 1 && a.g.tiles == 9 && act_ldb >= 5, HGV_EUNSUPPORTED,
                               "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
-    if (ntr_usable(a.g, M, A2 != nullptr)) {
+    if (ntr_usable(a.g, M, A2 != nullptr, act_bits != nullptr)) {
         rc = launch_ntr(a, stream);
     } else if (a.g.stream) {
         rc = launch_nths(a, stream);
@@ -1356,7 +1320,7 @@ extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const f
 extern "C" int hgv_gemm_nt16h_act_parts(int64_t M, int N, int K1, int K2) {
     GeoH g;
     if (M < 1) M = 1;
-    if (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && ntr_usable(g, M, K2 > 0)) return (int)ntr_grid(M);
+    if (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && ntr_usable(g, M, K2 > 0, true)) return (int)ntr_grid(M);
     int64_t wpb, blocks;
     nth_grid<9>(hgv_cdiv(M, 16), &wpb, &blocks);
     return (int)blocks;

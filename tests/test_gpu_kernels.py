@@ -658,7 +658,9 @@ def test_dual_linear_forward_backward(shape, projection_kind):
 @pytest.mark.parametrize("kind", ["f16x3", "bf16x6", "fp32"])
 @pytest.mark.parametrize("shape", [(160_984, 138, 138, 138), (160_984, 105, 105, 138), (131_072 + 7, 138, None, 56),
                                    (70_001, 276, None, 138), (100_003, 256, 256, 256), (40_001, 138, None, 138),
-                                   (32_768, 140, 129, 129), (32_767, 138, 138, 138), (50_000, 138, None, 112)])
+                                   (32_768, 140, 129, 129), (32_767, 138, 138, 138), (50_000, 138, None, 112),
+                                   (40_000, 28, None, 138), (40_003, 138, None, 28), (36_000, 64, 40, 100), (36_005, 144, 144, 144),
+                                   (33_000, 8, 8, 16), (40_000, 112, None, 138)])
 def test_projection_kernels_at_benchmark_rows(shape, kind):
     """Row counts of the benchmark shard: every wave of the resident-weight kernel streams several
     row tiles (the load ring runs across tile boundaries) and the weight-gradient kernel splits the
