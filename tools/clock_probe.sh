@@ -25,10 +25,10 @@ for r in rows:
         else: continue
     m = re.search(r"(k_\w+(<[^>]*>)?)", r["Kernel_Name"])
     key = m.group(1) if m else r["Kernel_Name"][:50]
-    a = acc[key]; a[0] += float(r["Counter_Value"]) / 8; a[1] += d / 8; a[2] += 0.125
+    a = acc[key]; a[0] += float(r["Counter_Value"]) / 8; a[1] += d; a[2] += 1          # one row per dispatch: the counter summed over the 8 XCDs
 with open("$out/clock.txt", "w") as f:
     for k, (cyc, ns, n) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         if ns > 0 and ns / n > 20000:
-            line = f"{k:44s} n={n:6.1f} avg {ns / n / 1e3:8.1f} us  {cyc / ns:5.2f} GHz"
+            line = f"{k:44s} n={n:4d} avg {ns / n / 1e3:8.1f} us  {cyc / ns:5.2f} GHz"
             print(line); f.write(line + "\n")
 PY
