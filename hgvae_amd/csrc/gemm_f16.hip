@@ -717,8 +717,11 @@ constexpr int NTR_EPT = 3;             // float4 per mover thread, source and bl
 #define NTR_SLOTS 2                    // blocks of loaded rows held in registers: one being staged, the others in flight (2, 3
                                        // and 4 take the same time where they fit the registers: the interval, not the memory latency, sets the pace)
 #endif
+// Smallest row count, in 16-row blocks per compute unit, that takes this kernel.  0: it is the faster one at every row count
+// it was measured at (138 rows: 16.4 against 20.4 us, no weight image to copy into LDS; 4 416 rows: 18.2 against 22.2 us;
+// 161 k rows: 69 against 75 us; 1.26 M rows: 380 against 560 us - all 138 + 138 -> 138)
 #ifndef NTR_MIN_BLOCKS_PER_WG
-#define NTR_MIN_BLOCKS_PER_WG 8
+#define NTR_MIN_BLOCKS_PER_WG 0
 #endif
 
 __host__ __device__ constexpr size_t ntr_astage_bytes(int chunks) { return (size_t)chunks * 2 * NTR_R * 64; }
@@ -1056,7 +1059,7 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
 #define NTR_ENABLE 1
 #endif
 // the register-weight kernel covers one-part images of three to nine column tiles over up to nine k chunks, sources of at most
-// 144 columns, from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards; the activated stores are built for the two
+// 144 columns (from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards); the activated stores are built for the two
 // shapes of the level tails (138 -> 129...144 and 138 + 138 -> 129...144)
 bool ntr_usable(const GeoH& g, int64_t M, bool two, bool act) {
     // (one or two column tiles: two multiplier waves do not keep four movers busy - 138 -> 28 takes 215 us here, 206 streaming)
