@@ -1058,13 +1058,15 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
 #ifndef NTR_ENABLE
 #define NTR_ENABLE 1
 #endif
-// the register-weight kernel covers one-part images of three to nine column tiles over up to nine k chunks, sources of at most
+// the register-weight kernel covers one-part images of three to nine column tiles over four to nine k chunks, sources of at most
 // 144 columns (from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards); the activated stores are built for the two
-// shapes of the level tails (138 -> 129...144 and 138 + 138 -> 129...144)
+// shapes of the level tails (129...144 -> 129...144 and 138 + 138 -> 129...144 columns)
 bool ntr_usable(const GeoH& g, int64_t M, bool two, bool act) {
     // (one or two column tiles: two multiplier waves do not keep four movers busy - 138 -> 28 takes 215 us here, 206 streaming)
     if (!NTR_ENABLE || g.stream || g.parts != 1 || g.tiles < 3 || g.tiles > 9 || g.chunks > 9 || g.K1 > 144 || g.K2 > 144) return false;
-    if (two ? g.chunks < 2 : g.chunks > 5) return false;
+    // short sources leave the movers (three float4 per lane and source, whatever its width) and the barrier per block with too
+    // little to amortise: 28 -> 138 at 1.26 M rows 286 against 252 us, 28 + 28 -> 138 334 against 277, 96 -> 138 304 against 325
+    if (g.chunks < 4 || (!two && g.chunks > 5)) return false;
     if (act && !((g.chunks == 5 && !two) || (g.chunks == 9 && two))) return false;
     return hgv_cdiv(M, NTR_R) >= (int64_t)NTR_MIN_BLOCKS_PER_WG * cu_count_h();
 }
@@ -1094,8 +1096,6 @@ int launch_ntr(const NtHArgs& a, hipStream_t st) {
     }
     if (a.A2) {
         switch (a.g.chunks) {
-            case 2: return launch_ntr_k<2, 2, 0>(a, st);
-            case 3: return launch_ntr_k<3, 2, 0>(a, st);
             case 4: return launch_ntr_k<4, 2, 0>(a, st);
             case 5: return launch_ntr_k<5, 2, 0>(a, st);
             case 6: return launch_ntr_k<6, 2, 0>(a, st);
@@ -1104,13 +1104,7 @@ int launch_ntr(const NtHArgs& a, hipStream_t st) {
             default: return launch_ntr_k<9, 2, 0>(a, st);
         }
     }
-    switch (a.g.chunks) {
-        case 1: return launch_ntr_k<1, 1, 0>(a, st);
-        case 2: return launch_ntr_k<2, 1, 0>(a, st);
-        case 3: return launch_ntr_k<3, 1, 0>(a, st);
-        case 4: return launch_ntr_k<4, 1, 0>(a, st);
-        default: return launch_ntr_k<5, 1, 0>(a, st);
-    }
+    return a.g.chunks == 4 ? launch_ntr_k<4, 1, 0>(a, st) : launch_ntr_k<5, 1, 0>(a, st);
 }
 
 template <int NT>

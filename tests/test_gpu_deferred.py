@@ -239,14 +239,14 @@ def test_projection_stores_the_activated_level_itself(op, relu, n_out, in_produc
 
 
 @pytest.mark.parametrize("p,offset", [(0.5, 0.0), (0.5, 300.0), (0.2, 300.0), (0.5, -1e4)])
-@pytest.mark.parametrize("n", [70001, 130])
-def test_in_product_statistics_with_a_large_common_offset(p, offset, n, monkeypatch):
+@pytest.mark.parametrize("n,k", [(70001, 138), (130, 138), (50_003, 28)])
+def test_in_product_statistics_with_a_large_common_offset(p, offset, n, k, monkeypatch):
     """The column sums taken inside the product are plain sums of d and d^2 per wave: a pre-activation whose mean is
     hundreds of standard deviations from zero (a large bias) must still give the batch statistics of the shifted sums of
     the statistics kernel - dropout's zeros are part of the variance, so mean^2 / variance of d stays below (1 - p) / p."""
     from hgvae_amd import functional as Fn
     from hgvae_amd.noise import PhiloxNoise, use_noise
-    k, n_out = 138, 138
+    n_out = 138
     gen = torch.Generator(device=dev()).manual_seed(int(offset) % 1000 + n)
     xa0 = _rand((n, k), gen)
     w = _rand((n_out, k), gen, 0.1)

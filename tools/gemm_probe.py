@@ -34,8 +34,11 @@ def main():
     shapes = [(138, 138, 138), (138, None, 138), (105, 105, 138), (138, 138, 56), (276, None, 138), (28, None, 138)]
     if os.environ.get("WIDE"):     # hidden width 256 (attention variant)
         shapes = [(256, 256, 256), (256, None, 256), (105, 105, 256), (256, None, 56)]
+    if os.environ.get("SHAPE"):        # "k1,k2,n" (k2 = 0: one source)
+        k1, k2, n = (int(v) for v in os.environ["SHAPE"].split(","))
+        shapes = [(k1, k2 or None, n)]
     only = os.environ.get("ONLY")
-    if only is not None:
+    if only is not None and not os.environ.get("SHAPE"):
         shapes = [shapes[int(only)]]
     for k1, k2, n in shapes:
         xa = new_padded(m, k1, dev); xa.normal_()
