@@ -668,6 +668,9 @@ namespace {
 // 144 outputs over a slice of the rows and writes its 81 accumulator tiles as a partial set;
 // k_reduce_tn16 adds the sets in fp64 in a fixed order and writes (or accumulates into) the final
 // matrices.
+#ifndef T16_INTERLEAVE
+#define T16_INTERLEAVE 1
+#endif
 constexpr int T16_ROWS = 32;
 constexpr int T16_PANEL = 1024 + 32;
 constexpr int T16_PIECE = 18 * T16_PANEL;
@@ -792,7 +795,76 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
     int* pace_mine = pace_tn + (a.pace_slot * PACE_WGS + blockIdx.x) * 16;
     const int* pace_twin = pace_tn + (a.pace_slot * PACE_WGS + (blockIdx.x ^ 8)) * 16;
     bool pace = a.paced != 0 && lead;
-    for (int64_t s = s_lo; s < s_hi; ++s) {
+    int64_t s = s_lo;
+#if T16_INTERLEAVE
+    // Steady steps (s + 2 exists, so neither the staged nor the loaded step is the ragged last one): the split of the next
+    // step's 12 values is cut into 36 slices of 3-4 VALU instructions, one behind each of the first 36 products, with the
+    // order fixed - a matrix-core instruction occupies its pipe for 16 cycles and the slice issues meanwhile.  Left to itself
+    // the compiler puts the whole split in front of an unbroken run of 36-54 products, every wave of the workgroup is in the
+    // same phase (one barrier per step), and the step costs the sum of the two.
+    for (; s + 2 < s_hi; ++s) {
+        const int b = (int)((s - s_lo) & 1);
+        const unsigned char* base = lds + b * T16_BUF;
+        unsigned char* wbase = lds + (b ^ 1) * T16_BUF;
+        int pace_seen = 0;
+        if (pace) pace_seen = __hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bf16x8 g[3][3], x[KT][3];      // [tile][piece]
+        // in the order the products need them (LDS returns in order: the first term starts after a third of the reads; the
+        // reads of a step are ~2 000 cycles of the compute unit's LDS pipe, as much as the products are of a SIMD's matrix pipe)
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int gp = o == 0 ? 2 : o - 1, xp = o == 0 ? 0 : 3 - o;          // (g2, x0), (g0, x2), (g1, x1)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) g[i][gp] = t16_read(base, gp * T16_PIECE + (3 * wn + i) * T16_PANEL + raddr);
+#pragma unroll
+            for (int j = 0; j < KT; ++j) x[j][xp] = t16_read(base, xp * T16_PIECE + (9 + k0t + j) * T16_PANEL + raddr);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int GP[6] = {2, 0, 1, 0, 1, 0}, XP[6] = {0, 2, 1, 1, 0, 0};      // small terms first
+        bf16x4 h4, m4, l4;
+        float r1 = 0.f;
+#pragma unroll
+        for (int idx = 0; idx < 6 * 3 * KT; ++idx) {
+            const int term = idx / (3 * KT), ij = idx - term * 3 * KT, i = ij / KT, j = ij - i * KT;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[i][GP[term]], x[j][XP[term]], acc[i][j], 0, 0, 0);
+            if (idx < 36) {
+                const int v = idx / 3, u = v >> 2, e = v & 3, part = idx - 3 * v;
+                if (part == 0) { h4[e] = (__bf16)stage[u][e]; r1 = stage[u][e] - (float)h4[e]; }
+                else if (part == 1) { m4[e] = (__bf16)r1; r1 = r1 - (float)m4[e]; }
+                else {
+                    l4[e] = (__bf16)r1;
+                    if (e == 3) {
+                        *reinterpret_cast<bf16x4*>(wbase + waddr[u]) = h4;
+                        *reinterpret_cast<bf16x4*>(wbase + T16_PIECE + waddr[u]) = m4;
+                        *reinterpret_cast<bf16x4*>(wbase + 2 * T16_PIECE + waddr[u]) = l4;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        load_step(s + 2);
+        if (bias) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int pc = 2; pc >= 0; --pc) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(g[i][pc], ones, accb[i], 0, 0, 0);
+        }
+        if (pace) {
+            const int done = (int)(s - s_lo) + 1;
+            if (lane == 0) __hip_atomic_store(pace_mine, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(pace_seen) < done - PACE_TN_AHEAD) {
+                for (int spin = 0;; ++spin) {
+                    const int seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(pace_twin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (seen >= done - PACE_TN_AHEAD) break;
+                    if (spin >= PACE_SPINS) { pace = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#endif
+    for (; s < s_hi; ++s) {
         const int b = (int)((s - s_lo) & 1);
         const unsigned char* base = lds + b * T16_BUF;
         int pace_seen = 0;
