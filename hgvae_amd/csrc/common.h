@@ -112,8 +112,11 @@ struct HgvPhilox {
         uint32_t a = k0, b = k1;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low one: the integer multiplies
+            // are quarter rate and all that these kernels wait for
+            const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+            const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+            const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
             const uint32_t n0 = hi1 ^ c1 ^ a, n2 = hi0 ^ c3 ^ b;
             c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
             a += 0x9E3779B9u; b += 0xBB67AE85u;
