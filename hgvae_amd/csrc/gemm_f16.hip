@@ -732,10 +732,13 @@ __host__ __device__ constexpr size_t ntr_lds_bytes(int chunks) {
 template <class F, int... Is>
 __device__ __forceinline__ void ntr_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 
-template <int CHUNKS, int NSRC, int ACT, int SLOTS>
-__global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
+// EPT: float4 per mover lane, source and block (3: sources up to 144 columns, 6: up to 288).  MAXT: threads of the largest
+// launch (registers: 13 waves leave 128 per lane, 12 leave 168).  Outputs past nine column tiles are split over blockIdx.y:
+// workgroup (x, y) owns the tiles y T ... y T + T - 1 (T = multiplier waves of the launch) and stages the rows again.
+template <int CHUNKS, int NSRC, int ACT, int SLOTS, int EPT = NTR_EPT, int MAXT = NTR_THREADS>
+__global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
     static_assert(SLOTS >= 2 && SLOTS <= 6, "register slots");
-    constexpr int R = NTR_R, EPT = NTR_EPT;
+    constexpr int R = NTR_R;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     HGV_GATE_EXIT(a);
     const GeoH& g = a.g;
@@ -757,8 +760,10 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
     const int64_t G = gridDim.x;
     const int64_t mine = (int64_t)blockIdx.x < nblocks ? (nblocks - 1 - blockIdx.x) / G + 1 : 0;
     auto block_of = [&](int64_t it) __attribute__((always_inline)) { return (int64_t)blockIdx.x + it * G; };
-    const int ntiles = g.tiles;                                      // multiplier waves; the four mover waves follow them
-    const int nc4 = (int)(min(a.ldc, (int64_t)16 * ntiles) / 4);
+    const int mwaves = ((int)blockDim.x - NTR_MOVERS) >> 6;          // multiplier waves; the four mover waves follow them
+    const int tile0 = (int)blockIdx.y * mwaves;                      // first column tile of this workgroup
+    const int ntiles = min(mwaves, g.tiles - tile0);                 // ... and how many it has (waves past them only keep the barriers)
+    const int nc4 = (int)(min(a.ldc - 16 * tile0, (int64_t)16 * ntiles) / 4);
     constexpr auto slots = std::make_integer_sequence<int, SLOTS>{};
     // intervals 0 ... mine, rounded up to one + a multiple of SLOTS (the slot of a block is a compile-time index): past the
     // end every step repeats the workgroup's last block - same loads, same staged bytes, same products, same stores
@@ -768,14 +773,18 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
     // Every wave passes the same barriers: two in front of the intervals, then one per interval it = 0 ... mine.  Interval it
     // holds, for the multiplier waves, the stores of block it - 1 and the products of block it, next to, for the mover waves,
     // the loads of block it + SLOTS and the scale + split + stage of block it + 1.
-    if (w < ntiles) {
+    if (w < mwaves) {
+        const bool idle = w >= ntiles;
         // ---- multiplier wave w: output columns 16 w ... 16 w + 15.  Lane (i, kq) holds image row 16 w + i, piece kq of every
         // chunk (a last tile stored without its dead rows repeats the last stored row; those outputs meet an inverse scale of zero)
         f16x8 wh[CHUNKS], wl[CHUNKS];
         {
-            const int rows = g.rows;
-            const int r = min(16 * w + i, rows - 1);
-            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)r * 64 + ((kq ^ ((r & 8) ? 3 : 0)) * 16);
+            // tile T of the image: row 16 T + i of a one-part image, row 16 (T mod tpp) + i of part T / tpp of a two-part one
+            const int rows = g.rows, T = min(tile0 + w, g.tiles - 1);
+            const int part = g.parts == 2 ? T / g.tpp : 0;
+            const int r = min(16 * (T - part * g.tpp) + i, rows - 1);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)part * part_bytes_h(rows, g.chunks) +
+                                       (size_t)r * 64 + ((kq ^ ((r & 8) ? 3 : 0)) * 16);
 #pragma unroll
             for (int c = 0; c < CHUNKS; ++c) {
                 wh[c] = *reinterpret_cast<const f16x8*>(src + (size_t)c * 2 * rows * 64);
@@ -784,10 +793,10 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
         }
         f32x4 invw4, bias4;
         {
-            const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + part_bytes_h(g.rows, g.chunks));
+            const float* invw = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.Wp) + (size_t)g.parts * part_bytes_h(g.rows, g.chunks));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = 16 * w + 4 * kq + r;
+                const int n = 16 * min(tile0 + w, g.tiles - 1) + 4 * kq + r;
                 invw4[r] = invw[n];
                 bias4[r] = (a.bias && n < g.N) ? a.bias[n] : 0.f;
             }
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
         // store element of this thread: float4 e = t of the block's R x nc4 float4 of output (64 per multiplier wave; threads
         // past the end repeat the last one), rows past the end of the matrix repeat its last row - same values, same address
         const int se = min(t, R * nc4 - 1), srow = se / nc4, scol = 4 * (se % nc4);
-        const int soff = srow * (int)a.ldc + scol;
+        const int soff = srow * (int)a.ldc + 16 * tile0 + scol;
         auto rows_over = [&](int64_t r0) __attribute__((always_inline)) {
             const int d = (int)max(r0 - (a.M - 1), (int64_t)-R);        // uniform: - R ... 0
             return max(d + srow, 0);
@@ -826,7 +835,7 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);          // the store leaves before the products start
-            {
+            if (!idle) {
                 const unsigned char* q = astage + (it & 1) * ASTAGE + qoff;
                 float* dst = cstage + (it & 1) * R * NTR_LDC;
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -867,7 +876,7 @@ __global__ __launch_bounds__(NTR_THREADS) void k_gemm_nt16r(const NtHArgs a) {
     } else {
         // ---- mover thread (row mr of the block, lane mj of the row's 16): float4 f = min(mj, 11) + 12 u (u = 0, 1, 2) of the row,
         // the last one repeated where the row is shorter - same loads, same staged bytes; lanes 12 ... 15 repeat lane 11
-        const int tl = t - ntiles * 64, mr = tl >> 4, mj = min(tl & 15, 11);
+        const int tl = t - mwaves * 64, mr = tl >> 4, mj = min(tl & 15, 11);
         int eoff[NSRC][EPT], ewr[NSRC][EPT];          // element offset (floats) from the block's first row; byte offset of its h halves in a stage buffer
 #pragma unroll
         for (int sidx = 0; sidx < NSRC; ++sidx) {
@@ -1058,53 +1067,70 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
 #ifndef NTR_ENABLE
 #define NTR_ENABLE 1
 #endif
-// the register-weight kernel covers one-part images of three to nine column tiles over four to nine k chunks, sources of at most
-// 144 columns (from NTR_MIN_BLOCKS_PER_WG row blocks per compute unit upwards); the activated stores are built for the two
-// shapes of the level tails (129...144 -> 129...144 and 138 + 138 -> 129...144 columns)
-bool ntr_usable(const GeoH& g, int64_t M, bool two, bool act) {
-    // (one or two column tiles: two multiplier waves do not keep four movers busy - 138 -> 28 takes 215 us here, 206 streaming)
-    if (!NTR_ENABLE || g.stream || g.parts != 1 || g.tiles < 3 || g.tiles > 9 || g.chunks > 9 || g.K1 > 144 || g.K2 > 144) return false;
-    // short sources leave the movers (three float4 per lane and source, whatever its width) and the barrier per block with too
-    // little to amortise: 28 -> 138 at 1.26 M rows 286 against 252 us, 28 + 28 -> 138 334 against 277, 96 -> 138 304 against 325
-    if (g.chunks < 4 || (!two && g.chunks > 5)) return false;
-    if (act && !((g.chunks == 5 && !two) || (g.chunks == 9 && two))) return false;
-    return hgv_cdiv(M, NTR_R) >= (int64_t)NTR_MIN_BLOCKS_PER_WG * cu_count_h();
+// The register-weight kernel covers 3 ... 18 column tiles (past nine they are split over two workgroups per row block),
+// four to nine k chunks from sources of at most 144 columns, and the two wide shapes of the hidden-width-256 model (256 -> N
+// and 256 + 256 -> N: 8 / 16 chunks, six float4 per mover lane and source, eight multiplier waves at most so that twelve waves
+// share the registers); the activated stores are built for the two shapes of the level tails (129...144 -> 129...144 and
+// 138 + 138 -> 129...144 columns).
+struct NtrPlan { bool ok; bool wide; int vparts, mwaves; };
+NtrPlan ntr_plan(const GeoH& g, int64_t M, bool two, bool act) {
+    NtrPlan p{false, false, 1, 0};
+    if (!NTR_ENABLE || g.tiles < 3 || g.tiles > 18) return p;
+    p.wide = g.K1 > 144 || g.K2 > 144;
+    if (p.wide) {
+        if (!((two && g.K1 == 256 && g.K2 == 256) || (!two && g.K1 == 256))) return p;
+    } else {
+        // short sources leave the movers (three float4 per lane and source, whatever its width) and the barrier per block with too
+        // little to amortise: 28 -> 138 at 1.26 M rows 286 against 252 us, 28 + 28 -> 138 334 against 277, 96 -> 138 304 against 325
+        if (g.chunks < 4 || g.chunks > 9 || (!two && g.chunks > 5)) return p;
+    }
+    const int per = p.wide ? 8 : 9;
+    p.vparts = (g.tiles + per - 1) / per;
+    p.mwaves = (g.tiles + p.vparts - 1) / p.vparts;
+    if (act && (p.vparts != 1 || p.wide || g.parts != 1 || !((g.chunks == 5 && !two) || (g.chunks == 9 && two)))) return p;
+    if (hgv_cdiv(M, NTR_R) < (int64_t)NTR_MIN_BLOCKS_PER_WG * cu_count_h()) return p;
+    p.ok = true;
+    return p;
 }
 #ifndef NTR_WGS_LIGHT
 #define NTR_WGS_LIGHT 1
 #endif
-// workgroups of a launch: one per compute unit.  The one-source product without activation needs few enough registers (72)
-// and LDS for two of them to share a compute unit: measured 3 % slower than one (320 against 309 us at 1.26 M rows)
-int64_t ntr_grid(int64_t M, bool light = false) {
-    const int64_t nblocks = hgv_cdiv(M, NTR_R), wgs = (int64_t)cu_count_h() * (light ? NTR_WGS_LIGHT : 1);
+// workgroups of a launch: one per compute unit (and column split).  The one-source product without activation needs few enough
+// registers (72) and LDS for two of them to share a compute unit: measured 3 % slower than one (320 against 309 us at 1.26 M rows)
+int64_t ntr_grid(int64_t M, int vparts = 1, bool light = false) {
+    const int64_t nblocks = hgv_cdiv(M, NTR_R);
+    int64_t wgs = (int64_t)cu_count_h() * (light ? NTR_WGS_LIGHT : 1) / vparts;
+    if (wgs < 1) wgs = 1;
     return nblocks < wgs ? nblocks : wgs;
 }
-template <int CHUNKS, int NSRC, int ACT>
-int launch_ntr_k(const NtHArgs& a, hipStream_t st) {
-    auto kern = k_gemm_nt16r<CHUNKS, NSRC, ACT, NTR_SLOTS>;
+template <int CHUNKS, int NSRC, int ACT, int EPT = NTR_EPT, int MAXT = NTR_THREADS>
+int launch_ntr_k(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
+    auto kern = k_gemm_nt16r<CHUNKS, NSRC, ACT, NTR_SLOTS, EPT, MAXT>;
     const int rc = raise_lds_h(kern);
     if (rc != HGV_OK) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)ntr_grid(a.M, CHUNKS <= 5 && ACT == 0)), dim3((unsigned)(64 * a.g.tiles + NTR_MOVERS)),
-                       ntr_lds_bytes(CHUNKS), st, a);
+    HGV_REQUIRE(64 * p.mwaves + NTR_MOVERS <= MAXT, HGV_ELAUNCH, "gemm_nt16h: %d multiplier waves do not fit this kernel", p.mwaves);
+    hipLaunchKernelGGL(kern, dim3((unsigned)ntr_grid(a.M, p.vparts, CHUNKS <= 5 && ACT == 0), (unsigned)p.vparts),
+                       dim3((unsigned)(64 * p.mwaves + NTR_MOVERS)), ntr_lds_bytes(CHUNKS), st, a);
     return HGV_OK;
 }
-int launch_ntr(const NtHArgs& a, hipStream_t st) {
+int launch_ntr(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
     if (a.act_bits) {
         const bool stats = a.stat_partial != nullptr;
-        if (a.A2) return stats ? launch_ntr_k<9, 2, 2>(a, st) : launch_ntr_k<9, 2, 1>(a, st);
-        return stats ? launch_ntr_k<5, 1, 2>(a, st) : launch_ntr_k<5, 1, 1>(a, st);
+        if (a.A2) return stats ? launch_ntr_k<9, 2, 2>(a, p, st) : launch_ntr_k<9, 2, 1>(a, p, st);
+        return stats ? launch_ntr_k<5, 1, 2>(a, p, st) : launch_ntr_k<5, 1, 1>(a, p, st);
     }
+    if (p.wide) return a.A2 ? launch_ntr_k<16, 2, 0, 6, 768>(a, p, st) : launch_ntr_k<8, 1, 0, 6, 768>(a, p, st);
     if (a.A2) {
         switch (a.g.chunks) {
-            case 4: return launch_ntr_k<4, 2, 0>(a, st);
-            case 5: return launch_ntr_k<5, 2, 0>(a, st);
-            case 6: return launch_ntr_k<6, 2, 0>(a, st);
-            case 7: return launch_ntr_k<7, 2, 0>(a, st);
-            case 8: return launch_ntr_k<8, 2, 0>(a, st);
-            default: return launch_ntr_k<9, 2, 0>(a, st);
+            case 4: return launch_ntr_k<4, 2, 0>(a, p, st);
+            case 5: return launch_ntr_k<5, 2, 0>(a, p, st);
+            case 6: return launch_ntr_k<6, 2, 0>(a, p, st);
+            case 7: return launch_ntr_k<7, 2, 0>(a, p, st);
+            case 8: return launch_ntr_k<8, 2, 0>(a, p, st);
+            default: return launch_ntr_k<9, 2, 0>(a, p, st);
         }
     }
-    return a.g.chunks == 4 ? launch_ntr_k<4, 1, 0>(a, st) : launch_ntr_k<5, 1, 0>(a, st);
+    return a.g.chunks == 4 ? launch_ntr_k<4, 1, 0>(a, p, st) : launch_ntr_k<5, 1, 0>(a, p, st);
 }
 
 template <int NT>
@@ -1270,8 +1296,9 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     if (act_bits) HGV_REQUIRE(!a.g.stream && a.g.parts == 1 && a.g.tiles == 9 && act_ldb >= 5, HGV_EUNSUPPORTED,
                               "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
-    if (ntr_usable(a.g, M, A2 != nullptr, act_bits != nullptr)) {
-        rc = launch_ntr(a, stream);
+    const NtrPlan plan = ntr_plan(a.g, M, A2 != nullptr, act_bits != nullptr);
+    if (plan.ok) {
+        rc = launch_ntr(a, plan, stream);
     } else if (a.g.stream) {
         rc = launch_nths(a, stream);
     } else {
@@ -1317,7 +1344,7 @@ extern "C" int hgv_gemm_nt16h_act(const float* A1, int64_t lda1, int K1, const f
 extern "C" int hgv_gemm_nt16h_act_parts(int64_t M, int N, int K1, int K2) {
     GeoH g;
     if (M < 1) M = 1;
-    if (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && ntr_usable(g, M, K2 > 0, true)) return (int)ntr_grid(M);
+    if (N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g) && ntr_plan(g, M, K2 > 0, true).ok) return (int)ntr_grid(M);
     int64_t wpb, blocks;
     nth_grid<9>(hgv_cdiv(M, 16), &wpb, &blocks);
     return (int)blocks;
