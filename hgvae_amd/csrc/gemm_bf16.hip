@@ -837,12 +837,14 @@ __device__ __forceinline__ void tn16_body(const Tn16Args& a, unsigned char* lds,
                         *reinterpret_cast<bf16x4*>(wbase + waddr[u]) = h4;
                         *reinterpret_cast<bf16x4*>(wbase + T16_PIECE + waddr[u]) = m4;
                         *reinterpret_cast<bf16x4*>(wbase + 2 * T16_PIECE + waddr[u]) = l4;
+                        // the float4 is spent: its successor (step s + 2) leaves now, a step ahead of its own split (at the end
+                        // of the step it would be wanted again a few hundred cycles later: 31 % of the wave cycles waited for it)
+                        stage[u] = *reinterpret_cast<const f32x4*>(src[u] + min((s + 2) * T16_ROWS, a.M - T16_ROWS) * ld[u]);
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        load_step(s + 2);
         if (bias) {
 #pragma unroll
             for (int i = 0; i < 3; ++i)
