@@ -1109,6 +1109,29 @@ extern "C" int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* 
     return HGV_OK;
 }
 
+// The two column sums of hgv_bn_act_bwd_pre_alg by themselves: sums[2][4 ceil(H / 4)] = (sum_i g_ic, sum_i g_ic xhat_ic) from
+// the consumers' parts, with dgamma / dbeta (nullable) written or added to as there.  For a consumer whose grad-input product
+// applies the level's backward to what it stores (hgv_gemm_nt16h_bwd).
+extern "C" int hgv_bn_bwd_sums_alg(int H, const float* save_mean, const float* save_rstd, int nparts, const float* const* W,
+                                   const int64_t* ldw, const float* const* raw, const int64_t* ldraw, const float* const* csum,
+                                   const int64_t* cs_stride, const int* n, float* sums, float* dgamma, float* dbeta, int accumulate,
+                                   hipStream_t stream) {
+    HGV_REQUIRE(H > 0 && H <= 2048 && save_mean && save_rstd && sums, HGV_EINVAL, "bn_bwd_sums_alg: bad arguments");
+    HGV_REQUIRE(nparts >= 1 && nparts <= ALG_MAX_PARTS && W && ldw && raw && ldraw && csum && cs_stride && n, HGV_EINVAL,
+                "bn_bwd_sums_alg: 1..%d parts expected", ALG_MAX_PARTS);
+    const int Hp = (H + 3) / 4 * 4;
+    AlgArgs q{};
+    q.nparts = nparts; q.H = H; q.Hp = Hp; q.mean = save_mean; q.rstd = save_rstd; q.sums = sums; q.dgamma = dgamma; q.dbeta = dbeta;
+    q.accumulate = accumulate;
+    for (int k = 0; k < nparts; ++k) {
+        HGV_REQUIRE(W[k] && raw[k] && csum[k] && n[k] > 0 && ldw[k] >= H && ldraw[k] >= H, HGV_EINVAL, "bn_bwd_sums_alg: bad part %d", k);
+        q.part[k] = AlgPart{W[k], ldw[k], raw[k], ldraw[k], csum[k], cs_stride[k], n[k]};
+    }
+    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+    HGV_CHECK_LAUNCH("bn_bwd_sums_alg");
+    return HGV_OK;
+}
+
 // ---- the same for two dropout draws of one pre-activation (the two encode passes of a train step over the shared first
 // convolution, gvae/gvae_skipcon.py:166-171): y is overwritten with the first draw's d, d2 receives the second's; one read
 // of y.  save_mean / save_rstd hold [2][H], col_s / col_t [2][4 * ceil(H / 4)]; the running statistics take the first

@@ -191,6 +191,12 @@ struct NtHArgs {
     // (1 - p) / p (the zeros it inserts are part of the variance), so nothing cancels as long as p is not small -
     // callers use this form from p = 0.2 upwards
     float* stat_partial; int stat_hp;
+    // backward of the level the product flows into (k_gemm_nt16r instantiated with ACT = 3): the product g = G W is the
+    // gradient with respect to the OUTPUT of a level relu? -> Dropout -> BatchNorm1d whose stored input is bwd_d (see act_bits
+    // for how relu / dropout are read off it), and what is stored is the gradient with respect to the level's pre-activation,
+    //   dy = k * gamma rstd (g - sum(g) / M - xhat sum(g xhat) / M),   xhat = (d - mean) rstd,
+    // with the two column sums in bwd_sums[2][stat_hp] (they are known before the product runs: hgv_bn_bwd_sums_alg).
+    const float* bwd_d; int64_t bwd_ldd; const float* bwd_gamma; const float* bwd_mean; const float* bwd_rstd; const float* bwd_sums;
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
@@ -725,8 +731,9 @@ constexpr int NTR_EPT = 3;             // float4 per mover thread, source and bl
 #endif
 
 __host__ __device__ constexpr size_t ntr_astage_bytes(int chunks) { return (size_t)chunks * 2 * NTR_R * 64; }
-__host__ __device__ constexpr size_t ntr_lds_bytes(int chunks) {
-    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 8 * 4;
+__host__ __device__ constexpr size_t ntr_lds_bytes(int chunks, int act = 0) {
+    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 8 * 4 +
+           (act == 3 ? (size_t)4 * NTR_R * NTR_LDC * 4 : 0);
 }
 
 template <class F, int... Is>
@@ -752,6 +759,8 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
     // loads are counted ones) and hand them over here: a load inside the multipliers' loop made every interval wait for the
     // completion of the store in front of it
     uint32_t* kbits = reinterpret_cast<uint32_t*>(rowinv + 2 * R);
+    // ACT = 3: the rows of d that belong to the last four blocks of output, [4][R][NTR_LDC], handed over by the movers likewise
+    float* dring = reinterpret_cast<float*>(kbits + 4 * R * 8);
     // columns the sources do not reach stay zero in both stage buffers for the whole launch (their weights are zero,
     // but 0 x garbage is not)
     for (int e = t; e < (int)(2 * ASTAGE / 16); e += (int)blockDim.x) reinterpret_cast<f32x4*>(astage)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -811,6 +820,25 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
         };
         f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};        // ACT = 2: sums of what this thread stored
         const int dropped = a.act_relu ? 0 : (int)0x80000000u;
+        // ACT = 3: the constants of this thread's four columns (columns past N store zeros)
+        f32x4 bw_a = f32x4{0.f, 0.f, 0.f, 0.f}, bw_mu = bw_a, bw_rs = bw_a, bw_sg = bw_a, bw_sgx = bw_a;
+        int bw_valid = 0;
+        if (ACT == 3) {
+            const float invn = 1.f / (float)a.M;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * tile0 + scol + r;
+                if (c < g.N) {
+                    const float rs = a.bwd_rstd[c];
+                    bw_valid |= 1 << r;
+                    bw_a[r] = (a.bwd_gamma ? a.bwd_gamma[c] : 1.f) * rs;
+                    bw_mu[r] = a.bwd_mean[c];
+                    bw_rs[r] = rs;
+                    bw_sg[r] = a.bwd_sums[c] * invn;
+                    bw_sgx[r] = a.bwd_sums[a.stat_hp + c] * invn;
+                }
+            }
+        }
         __syncthreads();
         __syncthreads();
         const int qoff = i * 64 + ((kq ^ ((i & 8) ? 3 : 0)) * 16);
@@ -819,7 +847,17 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 const int64_t r0 = block_of(min(it - 1, last)) * R;
                 const int over = rows_over(r0);
                 f32x4 o = *reinterpret_cast<const f32x4*>(cstage + ((it - 1) & 1) * R * NTR_LDC + srow * NTR_LDC + scol);
-                if (ACT) {
+                if (ACT == 3) {
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(dring + ((it - 1) & 3) * R * NTR_LDC + srow * NTR_LDC + scol);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (dv[r] - bw_mu[r]) * bw_rs[r];
+                        float dd = bw_a[r] * (o[r] - bw_sg[r] - xh * bw_sgx[r]);
+                        dd *= a.act_scale;
+                        const bool dead = a.act_relu ? !(dv[r] > 0.f) : __float_as_uint(dv[r]) == 0x80000000u;
+                        o[r] = (dead || !(bw_valid & (1 << r))) ? 0.f : dd;
+                    }
+                } else if (ACT) {
                     const uint32_t nib = kbits[(((it - 1) & 3) * R + srow) * 8 + (scol >> 5)] >> (scol & 31);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {          // keep bit -> all-ones / zero mask (v_bfe_i32), then a bit select (v_bfi_b32)
@@ -856,7 +894,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (acc[r] * inv) * invw4[r] + bias4[r];
-                if (ACT) {          // relu and the dropout scale here, the keep decision where the row is stored
+                if (ACT == 1 || ACT == 2) {          // relu and the dropout scale here, the keep decision where the row is stored
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = a.act_relu ? fmaxf(o[r], 0.f) : o[r];
@@ -891,8 +929,18 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             }
         }
         f32x4 raw[SLOTS][NSRC][EPT];
+        f32x4 draw[SLOTS][EPT];                       // ACT = 3: this lane's part of the row of d
+        int eoffd[EPT], dwr[EPT];
+        if (ACT == 3) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int f = min(mj + 12 * u, nc4 - 1);
+                eoffd[u] = mr * (int)a.bwd_ldd + 4 * f;
+                dwr[u] = mr * NTR_LDC + 4 * f;
+            }
+        }
         uint32_t kb[SLOTS];                           // ACT: word min(lane of the row, 7) of the row's keep bits
-        const int kword = min(min(tl & 15, 7), (int)a.act_ldb - 1);
+        const int kword = (ACT == 1 || ACT == 2) ? min(min(tl & 15, 7), (int)a.act_ldb - 1) : 0;
         // rows past the end of the matrix (last block of the launch) repeat its last row.  rows_over: rows of this thread past
         // the last row when its block starts at r0 (scalar part first: two VALU instructions)
         auto rows_over = [&](int64_t r0) __attribute__((always_inline)) {
@@ -910,7 +958,12 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) raw[S][sidx][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoff[sidx][u] - back));
             }
-            if (ACT) kb[S] = (a.act_bits + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
+            if (ACT == 3) {
+                const float* base = a.bwd_d + r0 * a.bwd_ldd;
+                const int back = over * (int)a.bwd_ldd;
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) draw[S][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoffd[u] - back));
+            } else if (ACT) kb[S] = (a.act_bits + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
         };
         // scale of the row from its largest entry (the row's 16 lanes hold all of it), split, stage; the inverse scale for the multipliers
         auto stage = [&](auto slot, int64_t it) __attribute__((always_inline)) {
@@ -922,7 +975,10 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(raw[S][sidx][u]));
-            if (ACT) asm volatile("" : "+v"(kb[S]));
+            if (ACT == 3) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(draw[S][u]));
+            } else if (ACT) asm volatile("" : "+v"(kb[S]));
             float m = 0.f;
 #pragma unroll
             for (int sidx = 0; sidx < NSRC; ++sidx)
@@ -938,7 +994,10 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             float inv;
             const float sc = scale_for(m, inv);
             rowinv[(it & 1) * R + mr] = inv;
-            if (ACT) kbits[((it & 3) * R + mr) * 8 + min(tl & 15, 7)] = kb[S];
+            if (ACT == 3) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) *reinterpret_cast<f32x4*>(dring + (it & 3) * R * NTR_LDC + dwr[u]) = draw[S][u];
+            } else if (ACT) kbits[((it & 3) * R + mr) * 8 + min(tl & 15, 7)] = kb[S];
             // elements two at a time: the split of eight values compiles to packed multiplies / conversions
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             constexpr int NE = NSRC * EPT;
@@ -1110,10 +1169,18 @@ int launch_ntr_k(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
     if (rc != HGV_OK) return rc;
     HGV_REQUIRE(64 * p.mwaves + NTR_MOVERS <= MAXT, HGV_ELAUNCH, "gemm_nt16h: %d multiplier waves do not fit this kernel", p.mwaves);
     hipLaunchKernelGGL(kern, dim3((unsigned)ntr_grid(a.M, p.vparts, CHUNKS <= 5 && ACT == 0), (unsigned)p.vparts),
-                       dim3((unsigned)(64 * p.mwaves + NTR_MOVERS)), ntr_lds_bytes(CHUNKS), st, a);
+                       dim3((unsigned)(64 * p.mwaves + NTR_MOVERS)), ntr_lds_bytes(CHUNKS, ACT), st, a);
     return HGV_OK;
 }
+// shapes whose product can store the backward of the level it flows into
+bool ntr_bwd_shape(const GeoH& g, const NtrPlan& p, bool two) {
+    return p.ok && !p.wide && p.vparts == 1 && g.N <= 144 && (two ? (g.chunks == 4 || g.chunks == 9) : (g.chunks == 4 || g.chunks == 5));
+}
 int launch_ntr(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
+    if (a.bwd_d) {
+        if (a.A2) return a.g.chunks == 4 ? launch_ntr_k<4, 2, 3>(a, p, st) : launch_ntr_k<9, 2, 3>(a, p, st);
+        return a.g.chunks == 4 ? launch_ntr_k<4, 1, 3>(a, p, st) : launch_ntr_k<5, 1, 3>(a, p, st);
+    }
     if (a.act_bits) {
         const bool stats = a.stat_partial != nullptr;
         if (a.A2) return stats ? launch_ntr_k<9, 2, 2>(a, p, st) : launch_ntr_k<9, 2, 1>(a, p, st);
@@ -1274,10 +1341,11 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 }
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
+struct NtHBwd { const float* d; int64_t ldd; const float* gamma; const float* mean; const float* rstd; const float* sums; };
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
                           hipStream_t stream, const uint32_t* act_bits = nullptr, int64_t act_ldb = 0, int act_relu = 0,
-                          float act_scale = 1.f, float* stat_partial = nullptr) {
+                          float act_scale = 1.f, float* stat_partial = nullptr, const NtHBwd* bwd = nullptr) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -1297,6 +1365,13 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
                               "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
     const NtrPlan plan = ntr_plan(a.g, M, A2 != nullptr, act_bits != nullptr);
+    if (bwd) {
+        HGV_REQUIRE(!act_bits && !bias && !gate && ntr_bwd_shape(a.g, plan, A2 != nullptr), HGV_EUNSUPPORTED,
+                    "gemm_nt16h_bwd: shape (%d + %d) -> %d is not one of the fused ones", K1, K2, N);
+        HGV_REQUIRE(bwd->d && hgv_aligned(bwd->d, 16) && bwd->ldd % 4 == 0 && bwd->ldd >= ldc && bwd->mean &&
+                    bwd->rstd && bwd->sums && ldc <= 144, HGV_EINVAL, "gemm_nt16h_bwd: bad/misaligned level buffers");
+        a.bwd_d = bwd->d; a.bwd_ldd = bwd->ldd; a.bwd_gamma = bwd->gamma; a.bwd_mean = bwd->mean; a.bwd_rstd = bwd->rstd; a.bwd_sums = bwd->sums;
+    }
     if (plan.ok) {
         rc = launch_ntr(a, plan, stream);
     } else if (a.g.stream) {
@@ -1357,6 +1432,29 @@ extern "C" int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, c
     HGV_REQUIRE(M >= 2, HGV_EINVAL, "gemm_nt16h_act_stats: statistics need at least two rows");
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, keep_bits, ld_bits, relu ? 1 : 0, scale,
                           stat_partial);
+}
+
+// 1 when hgv_gemm_nt16h_bwd can run this shape at M rows
+extern "C" int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2) {
+    GeoH g;
+    if (!(M > 0 && N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g))) return 0;
+    return ntr_bwd_shape(g, ntr_plan(g, M, K2 > 0, false), K2 > 0) ? 1 : 0;
+}
+
+// The grad-input product of a consumer whose operand was a level relu? -> Dropout -> BatchNorm1d handed over as its stored input
+// d [M, N] and per-column vectors: instead of g = A1 W1^T (+ A2 W2^T), the gradient with respect to the level's OUTPUT, it stores
+//   dy = k * gamma rstd (g - sums[0] / M - xhat sums[1] / M),  xhat = (d - mean) rstd,  k = 1 / (1 - p) where d was kept, else 0
+// (relu: kept = d > 0; otherwise dropped elements are the negative zeros) - the gradient with respect to the level's
+// pre-activation, what hgv_bn_act_bwd_pre_alg makes of g in a pass of its own.  sums[2][4 ceil(N / 4)]: column sums of g and of
+// g xhat over all M rows (hgv_bn_bwd_sums_alg); gamma nullable (ones).  dy needs ldc <= 144 and receives zeros in its pad columns.
+extern "C" int hgv_gemm_nt16h_bwd(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                  int64_t M, int N, float* dy, int64_t lddy, const float* d, int64_t ldd, int relu, float p,
+                                  const float* gamma, const float* mean, const float* rstd, const float* sums, hipStream_t stream) {
+    HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "gemm_nt16h_bwd: dropout p=%f outside [0,1)", p);
+    const NtHBwd b{d, ldd, gamma, mean, rstd, sums};
+    const float scale = 1.0f / (float)(1.0 - (double)p);          // as the level's own kernels form it
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, nullptr, M, N, dy, lddy, nullptr, 0, stream, nullptr, 0, relu ? 1 : 0, scale,
+                          nullptr, &b);
 }
 
 // hgv_gemm_nt16h that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the

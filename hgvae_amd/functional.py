@@ -201,11 +201,14 @@ class _GradParts:
     of G_p; with those of ALL consumers the level's backward needs no pass over the matrices to get the column sums of g
     and of g * xhat (hgv_bn_act_bwd_pre_alg).  ``uses`` counts the consumers that registered in the forward pass;
     ``tainted``: some consumer read the level another way (the written-out matrix, frozen weights, an aggregate of the
-    normalised operand), so the sums must be taken from the matrices."""
-    __slots__ = ("parts", "uses", "tainted")
+    normalised operand), so the sums must be taken from the matrices.  ``handles``: operators that took the level as
+    (d, s, t) in the forward pass; ``level``: what the level's backward needs (set by the level); ``fused``: the level's
+    backward as already applied by its only consumer's grad-input product (:func:`_grad_input`)."""
+    __slots__ = ("parts", "uses", "tainted", "handles", "level", "fused")
 
     def __init__(self):
         self.parts, self.uses, self.tainted = [], 0, False
+        self.handles, self.level, self.fused = 0, None, None
 
     def add(self, w, raw, csum) -> None:
         self.parts.append((w, raw, csum))
@@ -410,6 +413,8 @@ class _BnStats(torch.autograd.Function):
                       _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
                       ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (bool(relu), float(p))
+        if parts is not None and not fork:
+            parts.level = (d, gamma, beta, save_mean, save_rstd, bool(relu), float(p), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         ctx.save_for_backward(d, gamma, save_mean, save_rstd, beta)
         ctx.mark_non_differentiable(st, save_mean, save_rstd)
         ctx.set_materialize_grads(False)
@@ -427,18 +432,26 @@ class _BnStats(torch.autograd.Function):
         if g is None:
             return (None,) * 17
         n, h = d.shape
+        need = ctx.needs_input_grad
+        parts = ctx.parts
+        if parts is not None and parts.fused is not None:
+            # the only consumer's grad-input product has stored dy itself (and left dgamma / dbeta): pass it on
+            dy, dgamma, dbeta = parts.fused
+            parts.fused = None
+            parts.parts.clear()
+            if g2 is not None or g.data_ptr() != dy.data_ptr() or g.shape != dy.shape:
+                raise _lib.HgvError("a level's backward was applied by a product whose result is not the level's incoming gradient")
+            return (g, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 14
         g = rowmajor(g)
         g2 = rowmajor(g2) if g2 is not None else None
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, h), d.device, "bn")
         vec = is_vec4(d) and is_vec4(g) and (g2 is None or is_vec4(g2))
         dy = new_padded(n, h, d.device, zero_pad=not vec)
-        need = ctx.needs_input_grad
         gbuf, bbuf = (_grad_buffer(gamma) if need[1] else None), (_grad_buffer(beta) if need[2] else None)
         direct = gbuf is not None and bbuf is not None
         dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
         dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
-        parts = ctx.parts
         if _alg_sums and parts is not None and parts.complete() and all(w.size(1) == h for (w, _, _) in parts.parts):
             # every consumer was a projection on (d, s, t): the column sums come from their weight-gradient products
             nparts = len(parts.parts)
@@ -1308,6 +1321,57 @@ def _weight_grad2(g, xa, wa, xb, wb, bias=None, want_bias: bool = False):
     return _gemm_tn2(g, xa, xb, want_bias)
 
 
+_bwd_fuse = os.environ.get("HGVAE_BWD_FUSE", "1") != "0"        # 0: every level runs its backward pass itself (A/B)
+
+
+def _grad_input(g, img: _Image, g2, n_in: int, aff) -> torch.Tensor:
+    """The grad-input product  g W (+ g2 W2)  of an operator with respect to an operand of ``n_in`` columns.  When that
+    operand was a deferred level (``aff``) with this operator as its ONLY consumer, and the operator has already left its
+    weight-gradient parts (so the column sums of the level's backward are known), the product stores the level's dy
+    instead of its incoming gradient - relu / dropout / batch-norm backward applied on the way out, with d read once by
+    the product - and the level's backward pass over g and d disappears (``_GradParts.fused``)."""
+    parts = aff[2] if (aff is not None and len(aff) > 2) else None
+    lvl = parts.level if parts is not None else None
+    if (not _bwd_fuse or not _alg_sums or lvl is None or parts.handles != 1 or not parts.complete() or parts.fused is not None
+            or img.kind != "f16x3" or img.b is not None):
+        return _gemm_nt(g, img, g2, None, n_in)
+    d, gamma, beta, mean, rstd, relu, p, need_g, need_b = lvl
+    m, h = d.shape
+    lib = _lib.load()
+    k1, k2 = g.size(1), (g2.size(1) if g2 is not None else 0)
+    if (h != n_in or g.size(0) != m or ld_of(d) > 144 or not is_vec4(d) or any(w.size(1) != h for (w, _, _) in parts.parts)
+            or not lib.hgv_gemm_nt16h_bwd_supported(m, h, k1, k2)):
+        return _gemm_nt(g, img, g2, None, n_in)
+    if _CHECK_PADS:
+        _assert_zero_pads(g, g2)
+    nparts = len(parts.parts)
+    vp_t, i64_t, i32_t = _ctypes_arrays(nparts)
+    W, R, CS = vp_t(), vp_t(), vp_t()
+    ldw, ldr, css = i64_t(), i64_t(), i64_t()
+    nn_ = i32_t()
+    for q, (w, raw, cs) in enumerate(parts.parts):
+        W[q], R[q], CS[q] = w.data_ptr(), raw.data_ptr(), cs.data_ptr()
+        ldw[q], ldr[q], css[q], nn_[q] = w.stride(0), raw.stride(0), (cs.stride(0) if cs.numel() > 1 else 1), w.size(0)
+    gbuf, bbuf = (_grad_buffer(gamma) if need_g else None), (_grad_buffer(beta) if need_b else None)
+    direct = gbuf is not None and bbuf is not None
+    dgamma = gbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
+    dbeta = bbuf if direct else torch.empty(h, dtype=torch.float32, device=d.device)
+    sums = torch.empty(2, (h + 3) // 4 * 4, dtype=torch.float32, device=d.device)
+    _lib.call("hgv_bn_bwd_sums_alg", h, mean.data_ptr(), rstd.data_ptr(), nparts, W, ldw, R, ldr, CS, css, nn_, sums.data_ptr(),
+              dgamma.data_ptr(), dbeta.data_ptr(), 1 if direct else 0, _lib.stream())
+    dy = new_padded(m, h, d.device, zero_pad=False)
+    ev = _probe.add("nt", (m, k1 + k2, h)) if _probe is not None else None
+    if ev:
+        ev[0].record()
+    _lib.call("hgv_gemm_nt16h_bwd", g.data_ptr(), ld_of(g), k1, _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, k2, img.a.data_ptr(),
+              m, h, dy.data_ptr(), ld_of(dy), d.data_ptr(), ld_of(d), int(relu), float(p), _lib.ptr(gamma), mean.data_ptr(),
+              rstd.data_ptr(), sums.data_ptr(), _lib.stream())
+    if ev:
+        ev[1].record()
+    parts.fused = (dy, None if direct else dgamma, None if direct else dbeta)
+    return dy
+
+
 class _DualLinear(torch.autograd.Function):
     """y = xa @ Wa^T + xb @ Wb^T + bias on the matrix-core kernels (xb / Wb / bias optional).  ``aff_a`` / ``aff_b``: the
     (s, t) vectors of an operand that arrives un-normalised (see :class:`Deferred`)."""
@@ -1342,15 +1406,15 @@ class _DualLinear(torch.autograd.Function):
         need = ctx.needs_input_grad
         gxa = gxb = None
         want_bias = ctx.has_bias and need[4]
-        if need[0]:
-            gxa = _gemm_nt(g, ctx.pat, None, None, wa.size(1))
         ops = [(xa, wa, ctx.aff_a, need[1])]
         if ctx.has_b:
             ops.append((xb, wb, ctx.aff_b, need[3]))
-        gws, gb = _wgrad(g, ops, bias, want_bias)
+        gws, gb = _wgrad(g, ops, bias, want_bias)           # first: the operands' levels take their column sums from its parts
         gwa, gwb = gws[0], (gws[1] if ctx.has_b else None)
+        if need[0]:
+            gxa = _grad_input(g, ctx.pat, None, wa.size(1), ctx.aff_a)
         if ctx.has_b and need[2]:
-            gxb = _gemm_nt(g, ctx.pbt, None, None, wb.size(1))
+            gxb = _grad_input(g, ctx.pbt, None, wb.size(1), ctx.aff_b)
         return gxa, gwa, gxb, gwb, gb, None, None
 
 
@@ -1391,10 +1455,6 @@ class _ConcatLinear(torch.autograd.Function):
         g = as_padded(g)
         need = ctx.needs_input_grad
         gxa = gxb = gw = gb = None
-        if need[0]:
-            gxa = _gemm_nt(g, ctx.pat, None, None, ka)
-        if need[1]:
-            gxb = _gemm_nt(g, ctx.pbt, None, None, xb.size(1))
         want_bias = ctx.has_bias and need[3]
         if not need[2]:
             _taint(ctx.aff_a)
@@ -1428,6 +1488,11 @@ class _ConcatLinear(torch.autograd.Function):
                     gw = None
                 if direct:
                     gb = None
+        # behind the weight gradient: the operands' levels take their column sums from its parts
+        if need[0]:
+            gxa = _grad_input(g, ctx.pat, None, ka, ctx.aff_a)
+        if need[1]:
+            gxb = _grad_input(g, ctx.pbt, None, xb.size(1), ctx.aff_b)
         return gxa, gxb, gw, gb, None, None
 
 
@@ -1438,6 +1503,7 @@ def _unwrap(x, ok: bool):
             return x.tensor(), None
         if x.parts is not None:
             x.parts.uses += 1
+            x.parts.handles += 1
         return x.d, (x.s, x.t, x.parts)
     return x, None
 
@@ -1536,7 +1602,7 @@ class _SageConv(torch.autograd.Function):
             if ctx.aff is not None and len(ctx.aff) > 2 and ctx.aff[2] is not None:
                 ctx.aff[2].uses += 1                      # one consumer, two parts (g_x = aggT(g) wl + g wr)
             if need[0]:
-                gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
+                gx = _grad_input(gt, ctx.pt, g, n_in, ctx.aff)
         else:
             x, wl, wr, bl, agg = ctx.saved_tensors
             n_out, n_in = wl.shape
@@ -1567,7 +1633,7 @@ class _SageConv(torch.autograd.Function):
             if need[0] and ctx.pt is not None:
                 gt = new_padded(n, n_out, g.device, zero_pad=False)
                 _agg_launch(graph.by_src, n, g, n_out, 0, None, None, inv, None, gt)
-                gx = _gemm_nt(gt, ctx.pt, g, None, n_in)
+                gx = _grad_input(gt, ctx.pt, g, n_in, ctx.aff if ctx.ind else None)
             elif need[0]:
                 t = _gemm_nt(g, ctx.plt, None, None, n_in)
                 gr = _gemm_nt(g, ctx.prt, None, None, n_in)

@@ -427,6 +427,22 @@ int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* g2, int64_t
                            int nparts, const float* const* W, const int64_t* ldw, const float* const* raw, const int64_t* ldraw,
                            const float* const* csum, const int64_t* cs_stride, const int* n, float* dy, int64_t lddy,
                            float* dgamma, float* dbeta, int accumulate, void* ws, size_t ws_bytes, hgv_stream_t stream);
+/* The backward of a level (gvae/gvae_skipcon.py:124,130,136 and the head convolution's operand, :117-118) inside the grad-input
+ * product of its ONLY consumer.  hgv_bn_bwd_sums_alg: the two column sums of hgv_bn_act_bwd_pre_alg by themselves,
+ * sums[2][4 * ceil(H / 4)] = (sum_i g_ic, sum_i g_ic xhat_ic), dgamma / dbeta (nullable) written or added to.
+ * hgv_gemm_nt16h_bwd: hgv_gemm_nt16h (no bias) that stores, instead of g = A1 W1^T (+ A2 W2^T), the level's
+ *   dy = k * gamma rstd (g - sums[0] / M - xhat sums[1] / M),  xhat = (d - mean) rstd,  k = 1 / (1 - p) where d was kept, else 0
+ * (relu != 0: kept = d > 0, else the dropped elements are the negative zeros; gamma nullable = ones), i.e. what
+ * hgv_bn_act_bwd_pre_alg makes of g in a pass of its own.  Shapes: hgv_gemm_nt16h_bwd_supported (outputs of 33..144 columns
+ * from one source of 97..160 or two sources of 97..128 / 257..288 concatenated columns); lddy <= 144, ldd >= lddy; the pad columns of dy
+ * receive zeros. */
+int hgv_bn_bwd_sums_alg(int H, const float* save_mean, const float* save_rstd, int nparts, const float* const* W, const int64_t* ldw,
+                        const float* const* raw, const int64_t* ldraw, const float* const* csum, const int64_t* cs_stride,
+                        const int* n, float* sums, float* dgamma, float* dbeta, int accumulate, hgv_stream_t stream);
+int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2);
+int hgv_gemm_nt16h_bwd(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp, int64_t M,
+                       int N, float* dy, int64_t lddy, const float* d, int64_t ldd, int relu, float p, const float* gamma,
+                       const float* mean, const float* rstd, const float* sums, hgv_stream_t stream);
 /* The two-draw forms (the first level of the reference's two encode passes, gvae/gvae_skipcon.py:166-171, shares one
  * pre-activation): hgv_bn_stats_act2 overwrites y with the first draw's d and writes the second draw's to d2 over one read
  * of y (statistics [2][H], col_s / col_t [2][4 * ceil(H / 4)], running statistics updated for the first draw, then the

@@ -271,6 +271,64 @@ def test_in_product_statistics_with_a_large_common_offset(p, offset, n, k, monke
     assert float(((a[3].double() - b[3].double()).abs()).max()) <= 5e-6 * max(1.0, float((mean64.abs() * b[2].abs().double()[:n_out]).max()))
 
 
+@pytest.mark.parametrize("op", ["dual", "concat", "head", "sage"])
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("n", [3001, 40_007])
+def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch):
+    """hgv_bn_bwd_sums_alg + hgv_gemm_nt16h_bwd (the only consumer's grad-input product stores the level's dy) against the
+    product followed by hgv_bn_act_bwd_pre_alg: every gradient behind the level - its producer's input, weight and bias,
+    the batch-norm affine parameters - and the consumer's own are the same bits.  A level with a second consumer keeps
+    its own pass."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import graph_of
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    h = 138
+    gen = torch.Generator(device=dev()).manual_seed(n + int(relu))
+    ei, _, _ = path_batch([n])
+    ei = torch.cat([ei, torch.randint(0, n, (2, 4000))], 1).to(dev())
+    graph = graph_of(ei, n)
+    x0 = _rand((n, h), gen)
+    w0, b0 = _rand((h, h), gen, 0.1), _rand((h,), gen, 0.1)
+    other = _rand((n, h), gen)
+    n_out = {"dual": 105, "concat": 138, "head": 56, "sage": 138}[op]
+    w1, w2, b1 = _rand((n_out, h), gen, 0.1), _rand((n_out, h), gen, 0.1), _rand((n_out,), gen, 0.1)
+    gout = _rand((n, n_out), gen)
+    results = []
+    for fused, twice in ((True, False), (False, False), (True, True)):
+        monkeypatch.setattr(Fn, "_bwd_fuse", fused)
+        bn = _bn(h, torch.Generator(device=dev()).manual_seed(5))
+        x = x0.clone().requires_grad_(True)
+        wp, bp = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        wa, wb, b = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        monkeypatch.setattr(Fn._lib, "call", spy_call)
+        with use_noise(PhiloxNoise(99)), Fn.deferred_levels():
+            lvl = Fn.bn_level(lambda: Fn.dual_linear(x, wp, None, None, bp), bn, relu, 0.5, True, act_ok=True)
+            assert isinstance(lvl, Fn.Deferred)
+            if op == "dual":
+                y = Fn.dual_linear(lvl, wa, None, None, b)
+            elif op == "concat":
+                y = Fn.concat_linear(lvl, other, torch.cat([wa, wb], 1), b)
+            else:
+                y = Fn.sage_conv(lvl, graph, wa, b, wb, mean=True)
+            loss = (y * gout).sum()
+            if twice:                    # a second consumer of the same handle: the level runs its own backward pass
+                loss = loss + (Fn.dual_linear(lvl, wa[:, :h], None, None, None) * gout).sum() * 0.5
+            loss.backward()
+        monkeypatch.setattr(Fn._lib, "call", real_call)
+        assert ("hgv_gemm_nt16h_bwd" in names) == (fused and not twice), names
+        assert ("hgv_bn_act_bwd_pre_alg" in names) == (not fused or twice), names
+        results.append([t.grad.clone() for t in (x, wp, bp, bn.weight, bn.bias, wa, b)] + ([wb.grad.clone()] if wb.grad is not None else []))
+    for u, v in zip(results[0], results[1]):
+        assert torch.equal(u, v), (float((u - v).abs().max()), float(v.abs().max()))
+    assert all(bool(torch.isfinite(t).all()) for t in results[2])
+
+
 @pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
 def test_sage_convolution_on_a_deferred_operand(first, h_in):
     """SAGEConv over (d, s, t) = SAGEConv over the written-out d * s + t: forward, input gradient (with respect to `out`),
