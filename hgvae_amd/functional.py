@@ -413,7 +413,7 @@ class _BnStats(torch.autograd.Function):
                       _lib.ptr(tracked), save_mean.data_ptr(), save_rstd.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
                       ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (bool(relu), float(p))
-        if parts is not None and not fork:
+        if parts is not None:          # (a forked level whose second handle nobody takes has one consumer too)
             parts.level = (d, gamma, beta, save_mean, save_rstd, bool(relu), float(p), ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         ctx.save_for_backward(d, gamma, save_mean, save_rstd, beta)
         ctx.mark_non_differentiable(st, save_mean, save_rstd)

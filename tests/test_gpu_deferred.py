@@ -308,7 +308,9 @@ def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch)
             return _real(name, *a)
         monkeypatch.setattr(Fn._lib, "call", spy_call)
         with use_noise(PhiloxNoise(99)), Fn.deferred_levels():
-            lvl = Fn.bn_level(lambda: Fn.dual_linear(x, wp, None, None, bp), bn, relu, 0.5, True, act_ok=True)
+            forked = op in ("sage", "concat")        # a second handle that nobody takes leaves one consumer
+            lvl = Fn.bn_level(lambda: Fn.dual_linear(x, wp, None, None, bp), bn, relu, 0.5, True, act_ok=True, fork=forked)
+            lvl = lvl[0] if forked else lvl
             assert isinstance(lvl, Fn.Deferred)
             if op == "dual":
                 y = Fn.dual_linear(lvl, wa, None, None, b)
