@@ -991,17 +991,57 @@ def _start_level_bits(m: int, n_out: int, k1: int, k2: int, device) -> None:
     _act_ready = (m, n_out, relu, p, bits, words, done)
 
 
+_act_queue: list = []        # keep bits of the NEXT levels, in the order their products will ask for them (start_bits_ahead)
+_bits_ahead = os.environ.get("HGVAE_BITS_AHEAD", "1") != "0"    # 0: no keep bits are generated levels ahead (A/B)
+
+
+def start_bits_ahead(levels, training: bool, device) -> None:
+    """For a run of levels that follow each other with nothing stochastic in between (the decoder's three, gvae/gvae_skipcon.py:
+    121-137): ``levels`` = [(rows, n_out, k1, k2, relu, p), ...] in call order.  Their dropout draws are reserved now, in
+    that order - exactly the draws the levels would make one after the other - and the keep-bit kernels go to the side stream
+    at once, so all but the first run beside the products in front of them.  Stops at the first level whose product would not
+    store the activated level (it draws for itself, later, and nothing behind it may draw earlier)."""
+    drop_bits_ahead()
+    if (not _bits_ahead or not _bits_early or not _nt_act or not _defer or not training or not torch.is_grad_enabled()
+            or torch.cuda.is_current_stream_capturing() or on_branch_stream()):
+        return
+    lib = _lib.load()
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)
+    for (m, n_out, k1, k2, relu, p) in levels:
+        if p < DEFER_MIN_P or m < max(2, DEFER_MIN_ROWS) or not lib.hgv_gemm_nt16h_act_supported(n_out, k1, k2):
+            break
+        mask, seed, offset, ctr = current_noise().dropout((m, n_out), device)
+        words = ((n_out + 3) // 4 * 4 + 31) // 32
+        bits = torch.empty((m, words), dtype=torch.int32, device=device)
+        with torch.cuda.stream(side):
+            _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+            done = side.record_event()
+        bits.record_stream(side)
+        _act_queue.append((m, n_out, bool(relu), float(p), bits, words, done))
+
+
+def drop_bits_ahead() -> None:
+    """Forget keep bits prepared ahead that no product took (their draws stay reserved)."""
+    _act_queue.clear()
+
+
 def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> torch.Tensor:
     """out[M, n_out] = xa @ Wa^T (+ xb @ Wb^T) (+ bias) with the weight operand ``img`` (see :func:`_image`).
     xa / xb must already be in the padded layout.  ``level_out``: this product is the pre-activation a level asked for
     (see ``_act_request``)."""
-    global _act_done, _act_ready
+    global _act_done, _act_ready, _act_request
     m = xa.size(0)
     if _CHECK_PADS:
         _assert_zero_pads(xa, xb)
     out = new_padded(m, n_out, xa.device, zero_pad=False)
     ev = _probe.add("nt", (m, xa.size(1) + (xb.size(1) if xb is not None else 0), n_out)) if _probe is not None else None
     ready, _act_ready = (_act_ready, None) if level_out else (None, _act_ready)
+    if level_out and ready is None and _act_request is not None and _act_queue:
+        ready = _act_queue.pop(0)
+        if (ready[2], ready[3]) != (bool(_act_request[0]), float(_act_request[1])) or img.kind != "f16x3":
+            raise _lib.HgvError("keep bits prepared ahead do not belong to this level")
+        _act_request = None
     act = (_take_act(m, n_out, xa.size(1), xb.size(1) if xb is not None else 0, img.kind, xa.device)
            if (level_out and ready is None and _act_request is not None) else None)
     if ready is not None and (ready[0], ready[1]) != (m, n_out):

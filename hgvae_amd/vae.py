@@ -182,9 +182,15 @@ class SkipconVAE(_VAEBase):
 
     def decode(self, z, skip1, skip2):
         d1, d2, d3 = self.decoder1, self.decoder2, self.decoder3
-        h1 = self._linear_level(z, None, d1[0], d1[1], d1[2], relu=False)
-        h2 = self._linear_level(h1, skip1, d2[0], d2[1], d2[2], relu=False)
-        h3 = self._linear_level(h2, skip2, d3[0], d3[1], d3[2], relu=False)
+        rows, h = z.size(0), d1[0].out_features
+        Fn.start_bits_ahead([(rows, h, z.size(1), 0, False, d1[1].p), (rows, h, h, skip1.size(1), False, d2[1].p),
+                             (rows, h, h, skip2.size(1), False, d3[1].p)], self.training, z.device)
+        try:
+            h1 = self._linear_level(z, None, d1[0], d1[1], d1[2], relu=False)
+            h2 = self._linear_level(h1, skip1, d2[0], d2[1], d2[2], relu=False)
+            h3 = self._linear_level(h2, skip2, d3[0], d3[1], d3[2], relu=False)
+        finally:
+            Fn.drop_bits_ahead()
         return Fn.dual_linear(h3, d3[3].weight, None, None, d3[3].bias)
 
     def forward(self, x, edge_index, batch=None):

@@ -450,6 +450,53 @@ def test_train_step_with_deferred_levels_matches_the_plain_path(variant):
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-5, atol=1e-6), k
 
 
+def test_step_is_the_same_bits_with_and_without_the_overlaps_and_fusions(monkeypatch):
+    """At the benchmark's widths (105 features, hidden 138, latent 28) a whole train step gives the same loss and gradients, bit for bit,
+    whether the decoder's keep bits are generated levels ahead or in front of each product, and whether the levels with one
+    consumer have their backward applied by that consumer's grad-input product or by their own pass."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    from hgvae_amd import vae
+    gen = torch.Generator().manual_seed(11)
+    ei, n, batch = path_batch([700, 77, 300, 2, 45])
+    ei = torch.cat([ei, torch.randint(0, n, (2, 2000), generator=gen)], 1)
+    x = torch.randn(n, 105, generator=gen)
+    torch.manual_seed(11)
+    model = vae.SkipconVAE(105, 138, 28, 3).to(dev()).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    xd, eid, bd = x.to(dev()), ei.to(dev()), batch.to(dev())
+    results = []
+    for ahead, fuse in ((True, True), (False, True), (True, False), (False, False)):
+        monkeypatch.setattr(Fn, "_bits_ahead", ahead)
+        monkeypatch.setattr(Fn, "_bwd_fuse", fuse)
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        monkeypatch.setattr(Fn._lib, "call", spy_call)
+        with use_noise(PhiloxNoise(2024)):
+            loss = vae.train_step_loss(model, xd, eid, bd, 1.0)
+        loss.backward()
+        monkeypatch.setattr(Fn._lib, "call", real_call)
+        # fused: the three decoder levels, the third encoder level of both passes and the second pass's second level
+        assert names.count("hgv_gemm_nt16h_bwd") == (6 if fuse else 0), names.count("hgv_gemm_nt16h_bwd")
+        assert names.count("hgv_dropout_bits") == 7
+        assert not Fn._act_queue
+        results.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                        {k: b.clone() for k, b in model.named_buffers()}))
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0])
+        assert results[0][1].keys() == other[1].keys()
+        for k in other[1]:
+            assert torch.equal(results[0][1][k], other[1][k]), k
+        for k in other[2]:
+            assert torch.equal(results[0][2][k], other[2][k]), k
+
+
 @pytest.mark.parametrize("variant", ["skipcon", "attention"])
 def test_counter_noise_step_defers_the_shared_first_level_for_both_passes(variant):
     """With counter-based noise the first encoder level serves both encode passes from one pass over the convolution
