@@ -92,9 +92,9 @@ SIGNATURES = {
     "hgv_bn_act_bwd_pre_alg": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "hgv_bn_bwd_sums_alg": (C.c_int, [_i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "hgv_gemm_nt16h_bwd_supported": (C.c_int, [_i64, _i32, _i32, _i32]),
+    "hgv_gemm_nt16h_bwd_supported": (C.c_int, [_i64, _i32, _i32, _i32, _i32]),
     "hgv_gemm_nt16h_bwd": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp, _vp, _vp,
-                                     _vp, _vp]),
+                                     _vp, _vp, _i64, _vp]),
     "hgv_bn_stats_act2": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _u64, _u64, _u64, _vp, _vp, _vp, _f32, _vp, _vp, _f32, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "hgv_bn_act_bwd2_pre": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp,

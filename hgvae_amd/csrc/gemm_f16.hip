@@ -197,6 +197,8 @@ struct NtHArgs {
     //   dy = k * gamma rstd (g - sum(g) / M - xhat sum(g xhat) / M),   xhat = (d - mean) rstd,
     // with the two column sums in bwd_sums[2][stat_hp] (they are known before the product runs: hgv_bn_bwd_sums_alg).
     const float* bwd_d; int64_t bwd_ldd; const float* bwd_gamma; const float* bwd_mean; const float* bwd_rstd; const float* bwd_sums;
+    // ACT = 4: the same with g = G W + bwd_add (the level's other consumer has already written its share of the gradient)
+    const float* bwd_add; int64_t bwd_ldadd;
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
@@ -733,7 +735,7 @@ constexpr int NTR_EPT = 3;             // float4 per mover thread, source and bl
 __host__ __device__ constexpr size_t ntr_astage_bytes(int chunks) { return (size_t)chunks * 2 * NTR_R * 64; }
 __host__ __device__ constexpr size_t ntr_lds_bytes(int chunks, int act = 0) {
     return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 8 * 4 +
-           (act == 3 ? (size_t)4 * NTR_R * NTR_LDC * 4 : 0);
+           (act == 3 ? (size_t)4 * NTR_R * NTR_LDC * 4 : act == 4 ? (size_t)8 * NTR_R * NTR_LDC * 4 : 0);
 }
 
 template <class F, int... Is>
@@ -761,6 +763,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
     uint32_t* kbits = reinterpret_cast<uint32_t*>(rowinv + 2 * R);
     // ACT = 3: the rows of d that belong to the last four blocks of output, [4][R][NTR_LDC], handed over by the movers likewise
     float* dring = reinterpret_cast<float*>(kbits + 4 * R * 8);
+    float* addring = dring + 4 * R * NTR_LDC;                        // ACT = 4: ... and the rows of the addend
     // columns the sources do not reach stay zero in both stage buffers for the whole launch (their weights are zero,
     // but 0 x garbage is not)
     for (int e = t; e < (int)(2 * ASTAGE / 16); e += (int)blockDim.x) reinterpret_cast<f32x4*>(astage)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
         // ACT = 3: the constants of this thread's four columns (columns past N store zeros)
         f32x4 bw_a = f32x4{0.f, 0.f, 0.f, 0.f}, bw_mu = bw_a, bw_rs = bw_a, bw_sg = bw_a, bw_sgx = bw_a;
         int bw_valid = 0;
-        if (ACT == 3) {
+        if (ACT >= 3) {
             const float invn = 1.f / (float)a.M;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -847,8 +850,13 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 const int64_t r0 = block_of(min(it - 1, last)) * R;
                 const int over = rows_over(r0);
                 f32x4 o = *reinterpret_cast<const f32x4*>(cstage + ((it - 1) & 1) * R * NTR_LDC + srow * NTR_LDC + scol);
-                if (ACT == 3) {
+                if (ACT >= 3) {
                     const f32x4 dv = *reinterpret_cast<const f32x4*>(dring + ((it - 1) & 3) * R * NTR_LDC + srow * NTR_LDC + scol);
+                    if (ACT == 4) {
+                        const f32x4 av = *reinterpret_cast<const f32x4*>(addring + ((it - 1) & 3) * R * NTR_LDC + srow * NTR_LDC + scol);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += av[r];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xh = (dv[r] - bw_mu[r]) * bw_rs[r];
@@ -929,13 +937,15 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             }
         }
         f32x4 raw[SLOTS][NSRC][EPT];
-        f32x4 draw[SLOTS][EPT];                       // ACT = 3: this lane's part of the row of d
-        int eoffd[EPT], dwr[EPT];
-        if (ACT == 3) {
+        f32x4 draw[SLOTS][EPT];                       // ACT = 3, 4: this lane's part of the row of d
+        f32x4 aadd[SLOTS][EPT];                       // ACT = 4: ... and of the addend
+        int eoffd[EPT], eoffa[EPT], dwr[EPT];
+        if (ACT >= 3) {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
                 const int f = min(mj + 12 * u, nc4 - 1);
                 eoffd[u] = mr * (int)a.bwd_ldd + 4 * f;
+                if (ACT == 4) eoffa[u] = mr * (int)a.bwd_ldadd + 4 * f;
                 dwr[u] = mr * NTR_LDC + 4 * f;
             }
         }
@@ -958,11 +968,17 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) raw[S][sidx][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoff[sidx][u] - back));
             }
-            if (ACT == 3) {
+            if (ACT >= 3) {
                 const float* base = a.bwd_d + r0 * a.bwd_ldd;
                 const int back = over * (int)a.bwd_ldd;
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) draw[S][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoffd[u] - back));
+                if (ACT == 4) {
+                    const float* abase = a.bwd_add + r0 * a.bwd_ldadd;
+                    const int aback = over * (int)a.bwd_ldadd;
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) aadd[S][u] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(eoffa[u] - aback));
+                }
             } else if (ACT) kb[S] = (a.act_bits + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
         };
         // scale of the row from its largest entry (the row's 16 lanes hold all of it), split, stage; the inverse scale for the multipliers
@@ -975,9 +991,13 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(raw[S][sidx][u]));
-            if (ACT == 3) {
+            if (ACT >= 3) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(draw[S][u]));
+                if (ACT == 4) {
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(aadd[S][u]));
+                }
             } else if (ACT) asm volatile("" : "+v"(kb[S]));
             float m = 0.f;
 #pragma unroll
@@ -994,9 +1014,13 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             float inv;
             const float sc = scale_for(m, inv);
             rowinv[(it & 1) * R + mr] = inv;
-            if (ACT == 3) {
+            if (ACT >= 3) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) *reinterpret_cast<f32x4*>(dring + (it & 3) * R * NTR_LDC + dwr[u]) = draw[S][u];
+                if (ACT == 4) {
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) *reinterpret_cast<f32x4*>(addring + (it & 3) * R * NTR_LDC + dwr[u]) = aadd[S][u];
+                }
             } else if (ACT) kbits[((it & 3) * R + mr) * 8 + min(tl & 15, 7)] = kb[S];
             // elements two at a time: the split of eight values compiles to packed multiplies / conversions
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -1177,6 +1201,10 @@ bool ntr_bwd_shape(const GeoH& g, const NtrPlan& p, bool two) {
     return p.ok && !p.wide && p.vparts == 1 && g.N <= 144 && (two ? (g.chunks == 4 || g.chunks == 9) : (g.chunks == 4 || g.chunks == 5));
 }
 int launch_ntr(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
+    if (a.bwd_d && a.bwd_add) {
+        if (a.A2) return a.g.chunks == 9 ? launch_ntr_k<9, 2, 4>(a, p, st) : HGV_EUNSUPPORTED;
+        return a.g.chunks == 5 ? launch_ntr_k<5, 1, 4>(a, p, st) : HGV_EUNSUPPORTED;
+    }
     if (a.bwd_d) {
         if (a.A2) return a.g.chunks == 4 ? launch_ntr_k<4, 2, 3>(a, p, st) : launch_ntr_k<9, 2, 3>(a, p, st);
         return a.g.chunks == 4 ? launch_ntr_k<4, 1, 3>(a, p, st) : launch_ntr_k<5, 1, 3>(a, p, st);
@@ -1341,7 +1369,7 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 }
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
-struct NtHBwd { const float* d; int64_t ldd; const float* gamma; const float* mean; const float* rstd; const float* sums; };
+struct NtHBwd { const float* d; int64_t ldd; const float* gamma; const float* mean; const float* rstd; const float* sums; const float* add; int64_t ldadd; };
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
                           hipStream_t stream, const uint32_t* act_bits = nullptr, int64_t act_ldb = 0, int act_relu = 0,
@@ -1371,6 +1399,11 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
         HGV_REQUIRE(bwd->d && hgv_aligned(bwd->d, 16) && bwd->ldd % 4 == 0 && bwd->ldd >= ldc && bwd->mean &&
                     bwd->rstd && bwd->sums && ldc <= 144, HGV_EINVAL, "gemm_nt16h_bwd: bad/misaligned level buffers");
         a.bwd_d = bwd->d; a.bwd_ldd = bwd->ldd; a.bwd_gamma = bwd->gamma; a.bwd_mean = bwd->mean; a.bwd_rstd = bwd->rstd; a.bwd_sums = bwd->sums;
+        if (bwd->add) {
+            HGV_REQUIRE(hgv_aligned(bwd->add, 16) && bwd->ldadd % 4 == 0 && bwd->ldadd >= ldc && ((A2 && a.g.chunks == 9) || (!A2 && a.g.chunks == 5)),
+                        HGV_EUNSUPPORTED, "gemm_nt16h_bwd: an addend goes with 129..144 (+ 129..144) source columns only");
+            a.bwd_add = bwd->add; a.bwd_ldadd = bwd->ldadd;
+        }
     }
     if (plan.ok) {
         rc = launch_ntr(a, plan, stream);
@@ -1434,10 +1467,11 @@ extern "C" int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, c
                           stat_partial);
 }
 
-// 1 when hgv_gemm_nt16h_bwd can run this shape at M rows
-extern "C" int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2) {
+// 1 when hgv_gemm_nt16h_bwd can run this shape at M rows (addend != 0: with an addend)
+extern "C" int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2, int addend) {
     GeoH g;
     if (!(M > 0 && N > 0 && K1 > 0 && K2 >= 0 && geo_h(N, K1, K2, &g))) return 0;
+    if (addend && g.chunks != (K2 > 0 ? 9 : 5)) return 0;
     return ntr_bwd_shape(g, ntr_plan(g, M, K2 > 0, false), K2 > 0) ? 1 : 0;
 }
 
@@ -1447,11 +1481,14 @@ extern "C" int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2) {
 // (relu: kept = d > 0; otherwise dropped elements are the negative zeros) - the gradient with respect to the level's
 // pre-activation, what hgv_bn_act_bwd_pre_alg makes of g in a pass of its own.  sums[2][4 ceil(N / 4)]: column sums of g and of
 // g xhat over all M rows (hgv_bn_bwd_sums_alg); gamma nullable (ones).  dy needs ldc <= 144 and receives zeros in its pad columns.
+// addend (nullable, [M, N] with leading dimension ldadd): g = A1 W1^T (+ A2 W2^T) + addend - the share of the level's incoming
+// gradient that its other consumer has already written; only with one source of 129..160 columns or two of 129..144 each.
 extern "C" int hgv_gemm_nt16h_bwd(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                                   int64_t M, int N, float* dy, int64_t lddy, const float* d, int64_t ldd, int relu, float p,
-                                  const float* gamma, const float* mean, const float* rstd, const float* sums, hipStream_t stream) {
+                                  const float* gamma, const float* mean, const float* rstd, const float* sums, const float* addend,
+                                  int64_t ldadd, hipStream_t stream) {
     HGV_REQUIRE(p >= 0.f && p < 1.f, HGV_EINVAL, "gemm_nt16h_bwd: dropout p=%f outside [0,1)", p);
-    const NtHBwd b{d, ldd, gamma, mean, rstd, sums};
+    const NtHBwd b{d, ldd, gamma, mean, rstd, sums, addend, ldadd};
     const float scale = 1.0f / (float)(1.0 - (double)p);          // as the level's own kernels form it
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, nullptr, M, N, dy, lddy, nullptr, 0, stream, nullptr, 0, relu ? 1 : 0, scale,
                           nullptr, &b);

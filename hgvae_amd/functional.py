@@ -203,12 +203,14 @@ class _GradParts:
     ``tainted``: some consumer read the level another way (the written-out matrix, frozen weights, an aggregate of the
     normalised operand), so the sums must be taken from the matrices.  ``handles``: operators that took the level as
     (d, s, t) in the forward pass; ``level``: what the level's backward needs (set by the level); ``fused``: the level's
-    backward as already applied by its only consumer's grad-input product (:func:`_grad_input`)."""
-    __slots__ = ("parts", "uses", "tainted", "handles", "level", "fused")
+    backward as already applied by its only (or last) consumer's grad-input product (:func:`_grad_input`); ``pending``:
+    the shares of the incoming gradient that earlier consumers' products have written; ``shared``: one handle went to two
+    operators (autograd adds their gradients before the level sees them, so no product may stand in for the level)."""
+    __slots__ = ("parts", "uses", "tainted", "handles", "level", "fused", "pending", "shared")
 
     def __init__(self):
         self.parts, self.uses, self.tainted = [], 0, False
-        self.handles, self.level, self.fused = 0, None, None
+        self.handles, self.level, self.fused, self.pending, self.shared = 0, None, None, [], False
 
     def add(self, w, raw, csum) -> None:
         self.parts.append((w, raw, csum))
@@ -223,12 +225,13 @@ class Deferred:
     ``d`` is connected to the autograd graph; by convention the gradient that flows back into it is the gradient with
     respect to ``out`` (the consumers in this module compute exactly that).  ``tensor()`` writes ``out`` for a consumer
     that needs the matrix."""
-    __slots__ = ("d", "s", "t", "mean", "rstd", "gamma", "beta", "parts", "_out")
+    __slots__ = ("d", "s", "t", "mean", "rstd", "gamma", "beta", "parts", "_out", "taken")
 
     def __init__(self, d, s, t, mean, rstd, gamma, beta, parts=None):
         self.d, self.s, self.t, self.mean, self.rstd, self.gamma, self.beta = d, s, t, mean, rstd, gamma, beta
         self.parts = parts
         self._out = None
+        self.taken = 0               # operators that took this handle as (d, s, t)
 
     @property
     def shape(self):
@@ -437,8 +440,15 @@ class _BnStats(torch.autograd.Function):
         if parts is not None and parts.fused is not None:
             # the only consumer's grad-input product has stored dy itself (and left dgamma / dbeta): pass it on
             dy, dgamma, dbeta = parts.fused
+            waiting = len(parts.pending)
             parts.fused = None
             parts.parts.clear()
+            parts.pending.clear()
+            # the other gradient of a level with two consumers is the share the product has already added
+            if waiting == 1 and g2 is not None and g2.data_ptr() == dy.data_ptr():
+                g, g2 = g2, None
+            elif waiting == 1 and g2 is not None and g.data_ptr() == dy.data_ptr():
+                g2 = None
             if g2 is not None or g.data_ptr() != dy.data_ptr() or g.shape != dy.shape:
                 raise _lib.HgvError("a level's backward was applied by a product whose result is not the level's incoming gradient")
             return (g, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 14
@@ -473,6 +483,7 @@ class _BnStats(torch.autograd.Function):
                       ws.numel(), _lib.stream())
         if parts is not None:
             parts.parts.clear()
+            parts.pending.clear()
         if direct:
             dgamma = dbeta = None
         return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 14
@@ -1362,6 +1373,7 @@ def _weight_grad2(g, xa, wa, xb, wb, bias=None, want_bias: bool = False):
 
 
 _bwd_fuse = os.environ.get("HGVAE_BWD_FUSE", "1") != "0"        # 0: every level runs its backward pass itself (A/B)
+_bwd_fuse_add = os.environ.get("HGVAE_BWD_FUSE_ADD", "1") != "0"  # 0: ... every level with two consumers does (A/B)
 
 
 def _grad_input(g, img: _Image, g2, n_in: int, aff) -> torch.Tensor:
@@ -1372,15 +1384,25 @@ def _grad_input(g, img: _Image, g2, n_in: int, aff) -> torch.Tensor:
     the product - and the level's backward pass over g and d disappears (``_GradParts.fused``)."""
     parts = aff[2] if (aff is not None and len(aff) > 2) else None
     lvl = parts.level if parts is not None else None
-    if (not _bwd_fuse or not _alg_sums or lvl is None or parts.handles != 1 or not parts.complete() or parts.fused is not None
+    if (not _bwd_fuse or not _alg_sums or lvl is None or parts.handles not in (1, 2) or parts.tainted or parts.fused is not None
             or img.kind != "f16x3" or img.b is not None):
         return _gemm_nt(g, img, g2, None, n_in)
+    if parts.handles == 2 and (parts.shared or not _bwd_fuse_add):
+        return _gemm_nt(g, img, g2, None, n_in)
+    if parts.handles == 2 and not parts.complete():
+        # the first of two consumers (a level that also feeds a skip connection): its share is written as it is and waits
+        out = _gemm_nt(g, img, g2, None, n_in)
+        parts.pending.append(out)
+        return out
     d, gamma, beta, mean, rstd, relu, p, need_g, need_b = lvl
     m, h = d.shape
     lib = _lib.load()
     k1, k2 = g.size(1), (g2.size(1) if g2 is not None else 0)
-    if (h != n_in or g.size(0) != m or ld_of(d) > 144 or not is_vec4(d) or any(w.size(1) != h for (w, _, _) in parts.parts)
-            or not lib.hgv_gemm_nt16h_bwd_supported(m, h, k1, k2)):
+    add = parts.pending[0] if (parts.handles == 2 and len(parts.pending) == 1) else None
+    if (not parts.complete() or (parts.handles == 2 and add is None) or h != n_in or g.size(0) != m or ld_of(d) > 144 or not is_vec4(d)
+            or any(w.size(1) != h for (w, _, _) in parts.parts)
+            or not lib.hgv_gemm_nt16h_bwd_supported(m, h, k1, k2, 1 if add is not None else 0)
+            or (add is not None and (tuple(add.shape) != (m, h) or not is_vec4(add)))):
         return _gemm_nt(g, img, g2, None, n_in)
     if _CHECK_PADS:
         _assert_zero_pads(g, g2)
@@ -1405,7 +1427,7 @@ def _grad_input(g, img: _Image, g2, n_in: int, aff) -> torch.Tensor:
         ev[0].record()
     _lib.call("hgv_gemm_nt16h_bwd", g.data_ptr(), ld_of(g), k1, _lib.ptr(g2), ld_of(g2) if g2 is not None else 0, k2, img.a.data_ptr(),
               m, h, dy.data_ptr(), ld_of(dy), d.data_ptr(), ld_of(d), int(relu), float(p), _lib.ptr(gamma), mean.data_ptr(),
-              rstd.data_ptr(), sums.data_ptr(), _lib.stream())
+              rstd.data_ptr(), sums.data_ptr(), _lib.ptr(add), ld_of(add) if add is not None else 0, _lib.stream())
     if ev:
         ev[1].record()
     parts.fused = (dy, None if direct else dgamma, None if direct else dbeta)
@@ -1544,6 +1566,9 @@ def _unwrap(x, ok: bool):
         if x.parts is not None:
             x.parts.uses += 1
             x.parts.handles += 1
+            x.taken += 1
+            if x.taken > 1:
+                x.parts.shared = True
         return x.d, (x.s, x.t, x.parts)
     return x, None
 

@@ -435,14 +435,17 @@ int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* g2, int64_t
  * (relu != 0: kept = d > 0, else the dropped elements are the negative zeros; gamma nullable = ones), i.e. what
  * hgv_bn_act_bwd_pre_alg makes of g in a pass of its own.  Shapes: hgv_gemm_nt16h_bwd_supported (outputs of 33..144 columns
  * from one source of 97..160 or two sources of 97..128 / 257..288 concatenated columns); lddy <= 144, ldd >= lddy; the pad columns of dy
- * receive zeros. */
+ * receive zeros.  addend (nullable, [M, N], leading dimension ldadd): g = A1 W1^T (+ A2 W2^T) + addend, for a level with two
+ * consumers (a skip connection, gvae/gvae_skipcon.py:110-112 with :128-130) - the first consumer's grad-input product writes its
+ * share as usual, the second one's adds it and applies the level; one source of 129..160 or two of 129..144 columns only. */
 int hgv_bn_bwd_sums_alg(int H, const float* save_mean, const float* save_rstd, int nparts, const float* const* W, const int64_t* ldw,
                         const float* const* raw, const int64_t* ldraw, const float* const* csum, const int64_t* cs_stride,
                         const int* n, float* sums, float* dgamma, float* dbeta, int accumulate, hgv_stream_t stream);
-int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2);
+int hgv_gemm_nt16h_bwd_supported(int64_t M, int N, int K1, int K2, int addend);
 int hgv_gemm_nt16h_bwd(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp, int64_t M,
                        int N, float* dy, int64_t lddy, const float* d, int64_t ldd, int relu, float p, const float* gamma,
-                       const float* mean, const float* rstd, const float* sums, hgv_stream_t stream);
+                       const float* mean, const float* rstd, const float* sums, const float* addend, int64_t ldadd,
+                       hgv_stream_t stream);
 /* The two-draw forms (the first level of the reference's two encode passes, gvae/gvae_skipcon.py:166-171, shares one
  * pre-activation): hgv_bn_stats_act2 overwrites y with the first draw's d and writes the second draw's to d2 over one read
  * of y (statistics [2][H], col_s / col_t [2][4 * ceil(H / 4)], running statistics updated for the first draw, then the

@@ -271,14 +271,15 @@ def test_in_product_statistics_with_a_large_common_offset(p, offset, n, k, monke
     assert float(((a[3].double() - b[3].double()).abs()).max()) <= 5e-6 * max(1.0, float((mean64.abs() * b[2].abs().double()[:n_out]).max()))
 
 
-@pytest.mark.parametrize("op", ["dual", "concat", "head", "sage"])
+@pytest.mark.parametrize("op", ["dual", "concat", "concat1", "head", "sage"])
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("n", [3001, 40_007])
 def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch):
     """hgv_bn_bwd_sums_alg + hgv_gemm_nt16h_bwd (the only consumer's grad-input product stores the level's dy) against the
     product followed by hgv_bn_act_bwd_pre_alg: every gradient behind the level - its producer's input, weight and bias,
-    the batch-norm affine parameters - and the consumer's own are the same bits.  A level with a second consumer keeps
-    its own pass."""
+    the batch-norm affine parameters - and the consumer's own are the same bits.  With a second consumer the product that
+    runs last adds the share the first one wrote (one source of 129..160 columns or two of 129..144, each consumer on a
+    handle of its own); other shapes, and two consumers of one handle, leave the level its own pass."""
     from hgvae_amd import functional as Fn
     from hgvae_amd.graph import graph_of
     from hgvae_amd.noise import PhiloxNoise, use_noise
@@ -290,11 +291,11 @@ def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch)
     x0 = _rand((n, h), gen)
     w0, b0 = _rand((h, h), gen, 0.1), _rand((h,), gen, 0.1)
     other = _rand((n, h), gen)
-    n_out = {"dual": 105, "concat": 138, "head": 56, "sage": 138}[op]
+    n_out = {"dual": 105, "concat": 138, "concat1": 138, "head": 56, "sage": 138}[op]
     w1, w2, b1 = _rand((n_out, h), gen, 0.1), _rand((n_out, h), gen, 0.1), _rand((n_out,), gen, 0.1)
     gout = _rand((n, n_out), gen)
     results = []
-    for fused, twice in ((True, False), (False, False), (True, True)):
+    for fused, twice in ((True, False), (False, False), (True, True), (False, True)):
         monkeypatch.setattr(Fn, "_bwd_fuse", fused)
         bn = _bn(h, torch.Generator(device=dev()).manual_seed(5))
         x = x0.clone().requires_grad_(True)
@@ -310,25 +311,27 @@ def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch)
         with use_noise(PhiloxNoise(99)), Fn.deferred_levels():
             forked = op in ("sage", "concat")        # a second handle that nobody takes leaves one consumer
             lvl = Fn.bn_level(lambda: Fn.dual_linear(x, wp, None, None, bp), bn, relu, 0.5, True, act_ok=True, fork=forked)
-            lvl = lvl[0] if forked else lvl
+            lvl, lvl2 = lvl if forked else (lvl, lvl)
             assert isinstance(lvl, Fn.Deferred)
             if op == "dual":
                 y = Fn.dual_linear(lvl, wa, None, None, b)
-            elif op == "concat":
+            elif op in ("concat", "concat1"):
                 y = Fn.concat_linear(lvl, other, torch.cat([wa, wb], 1), b)
             else:
                 y = Fn.sage_conv(lvl, graph, wa, b, wb, mean=True)
             loss = (y * gout).sum()
-            if twice:                    # a second consumer of the same handle: the level runs its own backward pass
-                loss = loss + (Fn.dual_linear(lvl, wa[:, :h], None, None, None) * gout).sum() * 0.5
+            if twice:                    # a second consumer of the level (its backward runs first: the node is younger)
+                # through the level's second handle the two gradients reach it apart; through the same handle autograd adds them
+                loss = loss + (Fn.dual_linear(lvl2, wa[:, :h], None, None, None) * gout).sum() * 0.5
             loss.backward()
         monkeypatch.setattr(Fn._lib, "call", real_call)
-        assert ("hgv_gemm_nt16h_bwd" in names) == (fused and not twice), names
-        assert ("hgv_bn_act_bwd_pre_alg" in names) == (not fused or twice), names
+        applied = fused and (not twice or op in ("sage", "concat"))
+        assert ("hgv_gemm_nt16h_bwd" in names) == applied, names
+        assert ("hgv_bn_act_bwd_pre_alg" in names) == (not applied), names
         results.append([t.grad.clone() for t in (x, wp, bp, bn.weight, bn.bias, wa, b)] + ([wb.grad.clone()] if wb.grad is not None else []))
-    for u, v in zip(results[0], results[1]):
-        assert torch.equal(u, v), (float((u - v).abs().max()), float(v.abs().max()))
-    assert all(bool(torch.isfinite(t).all()) for t in results[2])
+    for a, b in ((0, 1), (2, 3)):
+        for u, v in zip(results[a], results[b]):
+            assert torch.equal(u, v), (a, float((u - v).abs().max()), float(v.abs().max()))
 
 
 @pytest.mark.parametrize("first,h_in", [(False, 138), (False, 140), (True, 138), (False, 61)])
@@ -482,8 +485,9 @@ def test_step_is_the_same_bits_with_and_without_the_overlaps_and_fusions(monkeyp
             loss = vae.train_step_loss(model, xd, eid, bd, 1.0)
         loss.backward()
         monkeypatch.setattr(Fn._lib, "call", real_call)
-        # fused: the three decoder levels, the third encoder level of both passes and the second pass's second level
-        assert names.count("hgv_gemm_nt16h_bwd") == (6 if fuse else 0), names.count("hgv_gemm_nt16h_bwd")
+        # fused: the three decoder levels, the third encoder level of both passes and the second level of both (in the first
+        # pass it also feeds a skip connection: the product that runs last adds the other's share)
+        assert names.count("hgv_gemm_nt16h_bwd") == (7 if fuse else 0), names.count("hgv_gemm_nt16h_bwd")
         assert names.count("hgv_dropout_bits") == 7
         assert not Fn._act_queue
         results.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
