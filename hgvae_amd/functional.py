@@ -995,6 +995,8 @@ def _start_level_bits(m: int, n_out: int, k1: int, k2: int, device) -> None:
     bits = torch.empty((m, words), dtype=torch.int32, device=device)
     main, side = torch.cuda.current_stream(device), _side_stream(device)
     side.wait_stream(main)                 # the buffer may be a recycled block whose last use is still queued on the main stream
+    if mask is not None:
+        mask.record_stream(side)           # an explicit mask lives until the side stream has read it
     with torch.cuda.stream(side):
         _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
         done = side.record_event()
@@ -1018,13 +1020,17 @@ def start_bits_ahead(levels, training: bool, device) -> None:
         return
     lib = _lib.load()
     main, side = torch.cuda.current_stream(device), _side_stream(device)
-    side.wait_stream(main)
     for (m, n_out, k1, k2, relu, p) in levels:
         if p < DEFER_MIN_P or m < max(2, DEFER_MIN_ROWS) or not lib.hgv_gemm_nt16h_act_supported(n_out, k1, k2):
             break
         mask, seed, offset, ctr = current_noise().dropout((m, n_out), device)
         words = ((n_out + 3) // 4 * 4 + 31) // 32
         bits = torch.empty((m, words), dtype=torch.int32, device=device)
+        # behind the draw: an explicit mask may still be on its way to the device on the main stream, and the bit buffer may
+        # be a recycled block whose last use is still queued there
+        side.wait_stream(main)
+        if mask is not None:
+            mask.record_stream(side)
         with torch.cuda.stream(side):
             _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
             done = side.record_event()

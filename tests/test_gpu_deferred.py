@@ -558,7 +558,8 @@ def test_counter_noise_step_defers_the_shared_first_level_for_both_passes(varian
 def test_skipcon_step_with_deferred_levels_matches_the_oracle(graph):
     """The oracle comparisons of tests/test_gpu_model.py, run with deferral at every size (the fixture of this file): with
     the oracle's explicit masks the step takes the same kernels as production - the projections store the activated
-    levels and their column sums, the backward sums come from the consumers' products."""
+    levels and their column sums, the backward sums come from the consumers' products, and the levels with projections as
+    consumers get their backward from those consumers' grad-input products."""
     import test_gpu_model as M
     from hgvae_amd import functional as Fn
     names = []
@@ -572,7 +573,8 @@ def test_skipcon_step_with_deferred_levels_matches_the_oracle(graph):
         M.test_skipcon_train_step_matches_oracle(graph)
     finally:
         Fn._lib.call = real_call
-    for expected in ("hgv_dropout_bits", "hgv_gemm_nt16h_act_stats", "hgv_bn_stats_merge", "hgv_bn_act_bwd_pre_alg", "hgv_agg_fwd_ind"):
+    for expected in ("hgv_dropout_bits", "hgv_gemm_nt16h_act_stats", "hgv_bn_stats_merge", "hgv_bn_act_bwd_pre_alg", "hgv_agg_fwd_ind",
+                     "hgv_bn_bwd_sums_alg", "hgv_gemm_nt16h_bwd"):
         assert expected in names, expected
 
 
