@@ -18,7 +18,7 @@ timeout -k 10 300 python3 bench.py --gpus 2 --workload protein32 --steps 10 --wa
 echo "2-rank rehearsal done"
 for w in protein32 protein256 attention32 pool; do
   d=$out/kt_$w; mkdir -p $d
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $d -o kt --output-format csv -- python3 bench.py --workload $w --steps 6 --warmup 3 --no-cpu-baseline > $d/bench.json 2> $d/err.log || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $d -o kt --output-format csv -- python3 bench.py --workload $w --steps 6 --warmup 3 --no-cpu-baseline --headline-only > $d/bench.json 2> $d/err.log || exit 1
   python3 tools/step_profile.py $d/kt_kernel_trace.csv 60 $d/seq.txt > $d/summary.txt || exit 1
   rm -f $d/kt_kernel_trace.csv
   echo "kernel trace $w done"
