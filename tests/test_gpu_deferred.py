@@ -273,8 +273,8 @@ def test_in_product_statistics_with_a_large_common_offset(p, offset, n, k, monke
 
 @pytest.mark.parametrize("op", ["dual", "concat", "concat1", "head", "sage"])
 @pytest.mark.parametrize("relu", [True, False])
-@pytest.mark.parametrize("n", [3001, 40_007])
-def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch):
+@pytest.mark.parametrize("n,h", [(3001, 138), (40_007, 138), (5003, 64), (2999, 129), (7, 138)])
+def test_grad_input_product_applies_the_level_backward(op, relu, n, h, monkeypatch):
     """hgv_bn_bwd_sums_alg + hgv_gemm_nt16h_bwd (the only consumer's grad-input product stores the level's dy) against the
     product followed by hgv_bn_act_bwd_pre_alg: every gradient behind the level - its producer's input, weight and bias,
     the batch-norm affine parameters - and the consumer's own are the same bits.  With a second consumer the product that
@@ -283,7 +283,8 @@ def test_grad_input_product_applies_the_level_backward(op, relu, n, monkeypatch)
     from hgvae_amd import functional as Fn
     from hgvae_amd.graph import graph_of
     from hgvae_amd.noise import PhiloxNoise, use_noise
-    h = 138
+    if op == "sage" and h != 138:
+        pytest.skip("the two-source product with the level's backward is built for sources of 129...144 columns")
     gen = torch.Generator(device=dev()).manual_seed(n + int(relu))
     ei, _, _ = path_batch([n])
     ei = torch.cat([ei, torch.randint(0, n, (2, 4000))], 1).to(dev())
