@@ -1034,24 +1034,27 @@ struct AlgArgs {
     const float* mean; const float* rstd;
     float* sums; float* dgamma; float* dbeta; int accumulate;
 };
-__global__ __launch_bounds__(256) void k_ep_bwd_sums_alg(const AlgArgs a) {
-    __shared__ double sh1[8][33], sh2[8][33];
+// 32 columns x 32 row groups per workgroup: a part of 138 rows is five rows per thread, all of them in flight at once (the
+// kernel is a chain of dependent-latency loads, not arithmetic: with eight row groups and four rows in flight it took 12 us)
+constexpr int ALG_GROUPS = 32;
+__global__ __launch_bounds__(32 * ALG_GROUPS) void k_ep_bwd_sums_alg(const AlgArgs a) {
+    __shared__ double sh1[ALG_GROUPS][33], sh2[ALG_GROUPS][33];
     const int cl = threadIdx.x & 31, ng = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < a.H) {
         for (int p = 0; p < a.nparts; ++p) {
             const AlgPart& q = a.part[p];
-            for (int n0 = ng; n0 < q.n; n0 += 32) {             // four rows of W in flight per thread
-                float w[4], r[4], s[4];
+            for (int n0 = ng; n0 < q.n; n0 += 8 * ALG_GROUPS) {             // eight rows of W in flight per thread
+                float w[8], r[8], s[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int n = min(n0 + 8 * u, q.n - 1);
+                for (int u = 0; u < 8; ++u) {
+                    const int n = min(n0 + ALG_GROUPS * u, q.n - 1);
                     w[u] = q.W[(int64_t)n * q.ldw + c]; r[u] = q.raw[(int64_t)n * q.ldraw + c]; s[u] = q.csum[(int64_t)n * q.cs_stride];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (n0 + 8 * u < q.n) { a1 += (double)w[u] * (double)s[u]; a2 += (double)w[u] * (double)r[u]; }
+                for (int u = 0; u < 8; ++u) {
+                    if (n0 + ALG_GROUPS * u < q.n) { a1 += (double)w[u] * (double)s[u]; a2 += (double)w[u] * (double)r[u]; }
                 }
             }
         }
@@ -1061,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_ep_bwd_sums_alg(const AlgArgs a) {
     if (ng == 0 && c < a.Hp) {
         double s1 = 0.0, sd = 0.0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += sh1[u][cl]; sd += sh2[u][cl]; }
+        for (int u = 0; u < ALG_GROUPS; ++u) { s1 += sh1[u][cl]; sd += sh2[u][cl]; }
         float f1 = 0.f, f2 = 0.f;
         if (c < a.H) {
             f1 = (float)s1;
@@ -1100,7 +1103,7 @@ extern "C" int hgv_bn_act_bwd_pre_alg(const float* g, int64_t ldg, const float* 
         HGV_REQUIRE(W[k] && raw[k] && csum[k] && n[k] > 0 && ldw[k] >= H && ldraw[k] >= H, HGV_EINVAL, "bn_act_bwd_pre_alg: bad part %d", k);
         q.part[k] = AlgPart{W[k], ldw[k], raw[k], ldraw[k], csum[k], cs_stride[k], n[k]};
     }
-    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(32 * ALG_GROUPS), 0, stream, q);
     BwdArgs b{g, ldg, g2, ldg2, save_mean, save_rstd, gamma, sums, dy, lddy, nullptr, 0, nullptr, 0};
     const bool vec = vec4_ok(d, ldd, Hp) && vec4_ok(g, ldg, Hp) && vec4_ok(g2, ldg2, Hp) && vec4_ok(dy, lddy, Hp);
     if (vec) hipLaunchKernelGGL((k_ep_bwd_apply<true, 1>), dim3(nb), dim3(256), 0, stream, a, b);
@@ -1127,7 +1130,7 @@ extern "C" int hgv_bn_bwd_sums_alg(int H, const float* save_mean, const float* s
         HGV_REQUIRE(W[k] && raw[k] && csum[k] && n[k] > 0 && ldw[k] >= H && ldraw[k] >= H, HGV_EINVAL, "bn_bwd_sums_alg: bad part %d", k);
         q.part[k] = AlgPart{W[k], ldw[k], raw[k], ldraw[k], csum[k], cs_stride[k], n[k]};
     }
-    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+    hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(32 * ALG_GROUPS), 0, stream, q);
     HGV_CHECK_LAUNCH("bn_bwd_sums_alg");
     return HGV_OK;
 }
@@ -1202,7 +1205,7 @@ extern "C" int hgv_bn_act_bwd2_pre(const float* g, int64_t ldg, const float* g2,
                 HGV_REQUIRE(W[j] && raw[j] && csum[j] && n[j] > 0 && ldw[j] >= H && ldraw[j] >= H, HGV_EINVAL, "bn_act_bwd2_pre: bad part %d", j);
                 q.part[k] = AlgPart{W[j], ldw[j], raw[j], ldraw[j], csum[j], cs_stride[j], n[j]};
             }
-            hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(256), 0, stream, q);
+            hipLaunchKernelGGL(k_ep_bwd_sums_alg, dim3((Hp + 31) / 32), dim3(32 * ALG_GROUPS), 0, stream, q);
             first += cnt;
         }
     } else {
