@@ -107,6 +107,10 @@ SIGNATURES = {
     "hgv_gemm_nt16h_act_parts": (C.c_int, [_i64, _i32, _i32, _i32]),
     "hgv_gemm_nt16h_act_stats": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f32, _vp,
                                            _vp]),
+    "hgv_gemm_nt16h_act2_supported": (C.c_int, [_i64, _i32, _i32, _i32]),
+    "hgv_gemm_nt16h_act2_parts": (C.c_int, [_i64]),
+    "hgv_gemm_nt16h_act2_stats": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _i64, _i32,
+                                            _f32, _vp, _vp, _vp]),
     "hgv_bn_stats_merge": (C.c_int, [_vp, _i32, _i32, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hgv_dropout_bits": (C.c_int, [_i64, _i32, _f32, _vp, _u64, _u64, _vp, _vp, _i64, _vp]),
     "hgv_bn_stats_pre": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -199,6 +199,10 @@ struct NtHArgs {
     const float* bwd_d; int64_t bwd_ldd; const float* bwd_gamma; const float* bwd_mean; const float* bwd_rstd; const float* bwd_sums;
     // ACT = 4: the same with g = G W + bwd_add (the level's other consumer has already written its share of the gradient)
     const float* bwd_add; int64_t bwd_ldadd;
+    // ACT = 5: the activated store with statistics for TWO dropout draws of the one product (the first level of the two encode
+    // passes of a train step, gvae/gvae_skipcon.py:166-171): C and stat_partial take the draw of act_bits, C2 and stat_partial2
+    // the draw of act_bits2 (same leading dimensions)
+    float* C2; const uint32_t* act_bits2; float* stat_partial2;
 };
 
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
@@ -734,7 +738,7 @@ constexpr int NTR_EPT = 3;             // float4 per mover thread, source and bl
 
 __host__ __device__ constexpr size_t ntr_astage_bytes(int chunks) { return (size_t)chunks * 2 * NTR_R * 64; }
 __host__ __device__ constexpr size_t ntr_lds_bytes(int chunks, int act = 0) {
-    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 8 * 4 +
+    return 2 * ntr_astage_bytes(chunks) + (size_t)2 * NTR_R * NTR_LDC * 4 + (size_t)2 * NTR_R * 4 + (size_t)4 * NTR_R * 16 * 4 +
            (act == 3 ? (size_t)4 * NTR_R * NTR_LDC * 4 : act == 4 ? (size_t)8 * NTR_R * NTR_LDC * 4 : 0);
 }
 
@@ -761,8 +765,10 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
     // loads are counted ones) and hand them over here: a load inside the multipliers' loop made every interval wait for the
     // completion of the store in front of it
     uint32_t* kbits = reinterpret_cast<uint32_t*>(rowinv + 2 * R);
+    constexpr bool BWD = ACT == 3 || ACT == 4, KEEP = ACT == 1 || ACT == 2 || ACT == 5, PAIR = ACT == 5;
+    constexpr int KW = 16;                                           // words per row in the ring: 8 per draw
     // ACT = 3: the rows of d that belong to the last four blocks of output, [4][R][NTR_LDC], handed over by the movers likewise
-    float* dring = reinterpret_cast<float*>(kbits + 4 * R * 8);
+    float* dring = reinterpret_cast<float*>(kbits + 4 * R * KW);
     float* addring = dring + 4 * R * NTR_LDC;                        // ACT = 4: ... and the rows of the addend
     // columns the sources do not reach stay zero in both stage buffers for the whole launch (their weights are zero,
     // but 0 x garbage is not)
@@ -782,6 +788,8 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
     const int64_t intervals = 1 + (mine + SLOTS - 1) / SLOTS * SLOTS;
     const int64_t last = mine > 0 ? mine - 1 : 0;
 
+    f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};        // ACT = 2, 5 (multipliers): sums of what this thread stored
+    f32x4 st1b = f32x4{0.f, 0.f, 0.f, 0.f}, st2b = f32x4{0.f, 0.f, 0.f, 0.f};      // ACT = 5: ... of the second draw
     // Every wave passes the same barriers: two in front of the intervals, then one per interval it = 0 ... mine.  Interval it
     // holds, for the multiplier waves, the stores of block it - 1 and the products of block it, next to, for the mover waves,
     // the loads of block it + SLOTS and the scale + split + stage of block it + 1.
@@ -821,12 +829,11 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             const int d = (int)max(r0 - (a.M - 1), (int64_t)-R);        // uniform: - R ... 0
             return max(d + srow, 0);
         };
-        f32x4 st1 = f32x4{0.f, 0.f, 0.f, 0.f}, st2 = f32x4{0.f, 0.f, 0.f, 0.f};        // ACT = 2: sums of what this thread stored
         const int dropped = a.act_relu ? 0 : (int)0x80000000u;
         // ACT = 3: the constants of this thread's four columns (columns past N store zeros)
         f32x4 bw_a = f32x4{0.f, 0.f, 0.f, 0.f}, bw_mu = bw_a, bw_rs = bw_a, bw_sg = bw_a, bw_sgx = bw_a;
         int bw_valid = 0;
-        if (ACT >= 3) {
+        if (BWD) {
             const float invn = 1.f / (float)a.M;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -850,7 +857,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 const int64_t r0 = block_of(min(it - 1, last)) * R;
                 const int over = rows_over(r0);
                 f32x4 o = *reinterpret_cast<const f32x4*>(cstage + ((it - 1) & 1) * R * NTR_LDC + srow * NTR_LDC + scol);
-                if (ACT >= 3) {
+                if (BWD) {
                     const f32x4 dv = *reinterpret_cast<const f32x4*>(dring + ((it - 1) & 3) * R * NTR_LDC + srow * NTR_LDC + scol);
                     if (ACT == 4) {
                         const f32x4 av = *reinterpret_cast<const f32x4*>(addring + ((it - 1) & 3) * R * NTR_LDC + srow * NTR_LDC + scol);
@@ -865,16 +872,31 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                         const bool dead = a.act_relu ? !(dv[r] > 0.f) : __float_as_uint(dv[r]) == 0x80000000u;
                         o[r] = (dead || !(bw_valid & (1 << r))) ? 0.f : dd;
                     }
-                } else if (ACT) {
-                    const uint32_t nib = kbits[(((it - 1) & 3) * R + srow) * 8 + (scol >> 5)] >> (scol & 31);
+                } else if (KEEP) {
+                    f32x4 o2 = o;
+                    if (PAIR) {          // the second draw of the same values
+                        const uint32_t nib2 = kbits[(((it - 1) & 3) * R + srow) * KW + 8 + (scol >> 5)] >> (scol & 31);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int keep = __builtin_amdgcn_sbfe(nib2, r, 1);
+                            o2[r] = __int_as_float((__float_as_int(o2[r]) & keep) | (dropped & ~keep));
+                        }
+                    }
+                    const uint32_t nib = kbits[(((it - 1) & 3) * R + srow) * KW + (scol >> 5)] >> (scol & 31);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {          // keep bit -> all-ones / zero mask (v_bfe_i32), then a bit select (v_bfi_b32)
                         const int keep = __builtin_amdgcn_sbfe(nib, r, 1);
                         o[r] = __int_as_float((__float_as_int(o[r]) & keep) | (dropped & ~keep));
                     }
+                    if (PAIR) {
+                        *reinterpret_cast<f32x4*>(a.C2 + r0 * a.ldc + (unsigned)(soff - over * (int)a.ldc)) = o2;
+                        const bool counts = it - 1 <= last && over == 0 && t < R * nc4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float d = counts ? o2[r] : 0.f; st1b[r] += d; st2b[r] += d * d; }
+                    }
                 }
                 *reinterpret_cast<f32x4*>(a.C + r0 * a.ldc + (unsigned)(soff - over * (int)a.ldc)) = o;
-                if (ACT == 2) {
+                if (ACT == 2 || PAIR) {
                     const bool counts = it - 1 <= last && over == 0 && t < R * nc4;          // the first and only time this element is stored
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float d = counts ? o[r] : 0.f; st1[r] += d; st2[r] += d * d; }
@@ -902,7 +924,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (acc[r] * inv) * invw4[r] + bias4[r];
-                if (ACT == 1 || ACT == 2) {          // relu and the dropout scale here, the keep decision where the row is stored
+                if (KEEP) {          // relu and the dropout scale here, the keep decision where the row is stored
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = a.act_relu ? fmaxf(o[r], 0.f) : o[r];
@@ -913,11 +935,6 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
                 *reinterpret_cast<f32x4*>(dst + i * NTR_LDC + 16 * w + 4 * kq) = o;
             }
             __syncthreads();
-        }
-        if (ACT == 2) {          // the stage buffers are dead: this thread's sums, for the addition over the rows below
-            float* red = reinterpret_cast<float*>(astage);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { red[t * 8 + r] = st1[r]; red[t * 8 + 4 + r] = st2[r]; }
         }
     } else {
         // ---- mover thread (row mr of the block, lane mj of the row's 16): float4 f = min(mj, 11) + 12 u (u = 0, 1, 2) of the row,
@@ -940,7 +957,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
         f32x4 draw[SLOTS][EPT];                       // ACT = 3, 4: this lane's part of the row of d
         f32x4 aadd[SLOTS][EPT];                       // ACT = 4: ... and of the addend
         int eoffd[EPT], eoffa[EPT], dwr[EPT];
-        if (ACT >= 3) {
+        if (BWD) {
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
                 const int f = min(mj + 12 * u, nc4 - 1);
@@ -950,7 +967,9 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             }
         }
         uint32_t kb[SLOTS];                           // ACT: word min(lane of the row, 7) of the row's keep bits
-        const int kword = (ACT == 1 || ACT == 2) ? min(min(tl & 15, 7), (int)a.act_ldb - 1) : 0;
+        // lane j of the row's sixteen: word min(j, 7) of the draw's keep bits (ACT = 5: lanes 8 ... 15 word j - 8 of the second draw's)
+        const int kword = KEEP ? min(PAIR ? (tl & 7) : min(tl & 15, 7), (int)a.act_ldb - 1) : 0;
+        const uint32_t* kbase = (PAIR && (tl & 8)) ? a.act_bits2 : a.act_bits;
         // rows past the end of the matrix (last block of the launch) repeat its last row.  rows_over: rows of this thread past
         // the last row when its block starts at r0 (scalar part first: two VALU instructions)
         auto rows_over = [&](int64_t r0) __attribute__((always_inline)) {
@@ -968,7 +987,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) raw[S][sidx][u] = *reinterpret_cast<const f32x4*>(base + (unsigned)(eoff[sidx][u] - back));
             }
-            if (ACT >= 3) {
+            if (BWD) {
                 const float* base = a.bwd_d + r0 * a.bwd_ldd;
                 const int back = over * (int)a.bwd_ldd;
 #pragma unroll
@@ -979,7 +998,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
 #pragma unroll
                     for (int u = 0; u < EPT; ++u) aadd[S][u] = *reinterpret_cast<const f32x4*>(abase + (unsigned)(eoffa[u] - aback));
                 }
-            } else if (ACT) kb[S] = (a.act_bits + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
+            } else if (KEEP) kb[S] = (kbase + r0 * a.act_ldb)[(unsigned)((mr - over) * (int)a.act_ldb + kword)];
         };
         // scale of the row from its largest entry (the row's 16 lanes hold all of it), split, stage; the inverse scale for the multipliers
         auto stage = [&](auto slot, int64_t it) __attribute__((always_inline)) {
@@ -991,14 +1010,14 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             for (int sidx = 0; sidx < NSRC; ++sidx)
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(raw[S][sidx][u]));
-            if (ACT >= 3) {
+            if (BWD) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(draw[S][u]));
                 if (ACT == 4) {
 #pragma unroll
                     for (int u = 0; u < EPT; ++u) asm volatile("" : "+v"(aadd[S][u]));
                 }
-            } else if (ACT) asm volatile("" : "+v"(kb[S]));
+            } else if (KEEP) asm volatile("" : "+v"(kb[S]));
             float m = 0.f;
 #pragma unroll
             for (int sidx = 0; sidx < NSRC; ++sidx)
@@ -1014,14 +1033,14 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             float inv;
             const float sc = scale_for(m, inv);
             rowinv[(it & 1) * R + mr] = inv;
-            if (ACT >= 3) {
+            if (BWD) {
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) *reinterpret_cast<f32x4*>(dring + (it & 3) * R * NTR_LDC + dwr[u]) = draw[S][u];
                 if (ACT == 4) {
 #pragma unroll
                     for (int u = 0; u < EPT; ++u) *reinterpret_cast<f32x4*>(addring + (it & 3) * R * NTR_LDC + dwr[u]) = aadd[S][u];
                 }
-            } else if (ACT) kbits[((it & 3) * R + mr) * 8 + min(tl & 15, 7)] = kb[S];
+            } else if (KEEP) kbits[((it & 3) * R + mr) * KW + (PAIR ? (tl & 15) : min(tl & 15, 7))] = kb[S];
             // elements two at a time: the split of eight values compiles to packed multiplies / conversions
             typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
             constexpr int NE = NSRC * EPT;
@@ -1058,10 +1077,18 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
         for (int64_t it = 1; it < intervals; it += SLOTS)
             ntr_for([&](auto k) __attribute__((always_inline)) { interval(std::integral_constant<int, (decltype(k)::value + 1) % SLOTS>{}, it + decltype(k)::value); }, slots);
     }
-    if (ACT == 2) {
-        // per column: the sums of the 16 threads that stored it, added in row order; workgroup b of G holds the 16-row groups b, b + G, ...
+    constexpr int NSETS = PAIR ? 2 : (ACT == 2 ? 1 : 0);
+#pragma unroll
+    for (int set = 0; set < NSETS; ++set) {
+        // the stage buffers are dead: every multiplier thread's sums, then per column the sums of the 16 threads that stored it,
+        // added in row order; workgroup b of G holds the 16-row groups b, b + G, ...
+        float* red = reinterpret_cast<float*>(astage);
+        if (set) __syncthreads();          // the first draw's sums have been read
+        if (w < mwaves) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { red[t * 8 + r] = set ? st1b[r] : st1[r]; red[t * 8 + 4 + r] = set ? st2b[r] : st2[r]; }
+        }
         __syncthreads();
-        const float* red = reinterpret_cast<const float*>(astage);
         const int ncol = 4 * nc4;
         if (t < ncol) {
             double s1 = 0.0, s2 = 0.0;
@@ -1072,7 +1099,7 @@ __global__ __launch_bounds__(MAXT) void k_gemm_nt16r(const NtHArgs a) {
             const int64_t part = blockIdx.x;
             const int64_t groups = part < nblocks ? (nblocks - 1 - part) / G + 1 : 0;
             const double nrows = (double)(groups * 16 - ((groups > 0 && (nblocks - 1) % G == part) ? nblocks * 16 - a.M : 0));
-            float* dst = a.stat_partial + part * 2 * a.stat_hp;
+            float* dst = (set ? a.stat_partial2 : a.stat_partial) + part * 2 * a.stat_hp;
             if (t < a.stat_hp) {
                 dst[t] = groups > 0 ? (float)(s1 / nrows) : 0.f;
                 dst[a.stat_hp + t] = groups > 0 ? (float)(s2 - s1 * s1 / nrows) : 0.f;
@@ -1156,7 +1183,7 @@ int launch_nth_part(const NtHArgs& a, int part, int nt, size_t lds, hipStream_t 
 // share the registers); the activated stores are built for the two shapes of the level tails (129...144 -> 129...144 and
 // 138 + 138 -> 129...144 columns).
 struct NtrPlan { bool ok; bool wide; int vparts, mwaves; };
-NtrPlan ntr_plan(const GeoH& g, int64_t M, bool two, bool act) {
+NtrPlan ntr_plan(const GeoH& g, int64_t M, bool two, bool act, bool pair = false) {
     NtrPlan p{false, false, 1, 0};
     if (!NTR_ENABLE || g.tiles < 3 || g.tiles > 18) return p;
     p.wide = g.K1 > 144 || g.K2 > 144;
@@ -1170,7 +1197,8 @@ NtrPlan ntr_plan(const GeoH& g, int64_t M, bool two, bool act) {
     const int per = p.wide ? 8 : 9;
     p.vparts = (g.tiles + per - 1) / per;
     p.mwaves = (g.tiles + p.vparts - 1) / p.vparts;
-    if (act && (p.vparts != 1 || p.wide || g.parts != 1 || !((g.chunks == 5 && !two) || (g.chunks == 9 && two)))) return p;
+    if (act && !pair && (p.vparts != 1 || p.wide || g.parts != 1 || !((g.chunks == 5 && !two) || (g.chunks == 9 && two)))) return p;
+    if (pair && (p.vparts != 1 || p.wide || g.parts != 1 || g.tiles != 9 || !(g.chunks == 7 && two))) return p;          // 97...112 + 97...112 -> 129...144
     if (hgv_cdiv(M, NTR_R) < (int64_t)NTR_MIN_BLOCKS_PER_WG * cu_count_h()) return p;
     p.ok = true;
     return p;
@@ -1201,6 +1229,7 @@ bool ntr_bwd_shape(const GeoH& g, const NtrPlan& p, bool two) {
     return p.ok && !p.wide && p.vparts == 1 && g.N <= 144 && (two ? (g.chunks == 4 || g.chunks == 9) : (g.chunks == 4 || g.chunks == 5));
 }
 int launch_ntr(const NtHArgs& a, const NtrPlan& p, hipStream_t st) {
+    if (a.act_bits2) return launch_ntr_k<7, 2, 5>(a, p, st);
     if (a.bwd_d && a.bwd_add) {
         if (a.A2) return a.g.chunks == 9 ? launch_ntr_k<9, 2, 4>(a, p, st) : HGV_EUNSUPPORTED;
         return a.g.chunks == 5 ? launch_ntr_k<5, 1, 4>(a, p, st) : HGV_EUNSUPPORTED;
@@ -1369,11 +1398,12 @@ extern "C" int hgv_pack16h_weights_affine(const float* W1, int64_t sn1, int64_t 
 }
 
 // C[M,N] = A1 W1^T (+ A2 W2^T) (+ bias) from the scaled fp16 image.  Buffer rules as for hgv_gemm_nt16.
+struct NtHPair { float* C2; const uint32_t* bits2; float* partial2; };
 struct NtHBwd { const float* d; int64_t ldd; const float* gamma; const float* mean; const float* rstd; const float* sums; const float* add; int64_t ldadd; };
 static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                           const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int gate_run_if,
                           hipStream_t stream, const uint32_t* act_bits = nullptr, int64_t act_ldb = 0, int act_relu = 0,
-                          float act_scale = 1.f, float* stat_partial = nullptr, const NtHBwd* bwd = nullptr) {
+                          float act_scale = 1.f, float* stat_partial = nullptr, const NtHBwd* bwd = nullptr, const NtHPair* pair = nullptr) {
     HGV_REQUIRE(M >= 0 && N > 0 && K1 > 0, HGV_EINVAL, "gemm_nt16h: bad sizes");
     if (M == 0) return HGV_OK;
     NtHArgs a{};
@@ -1392,7 +1422,13 @@ static int gemm_nt16h_any(const float* A1, int64_t lda1, int K1, const float* A2
     if (act_bits) HGV_REQUIRE(!a.g.stream && a.g.parts == 1 && a.g.tiles == 9 && act_ldb >= 5, HGV_EUNSUPPORTED,
                               "gemm_nt16h_act: only one-part images of 9 column tiles (129..144 outputs) store activated");
     int rc;
-    const NtrPlan plan = ntr_plan(a.g, M, A2 != nullptr, act_bits != nullptr);
+    const NtrPlan plan = ntr_plan(a.g, M, A2 != nullptr, act_bits != nullptr, pair != nullptr);
+    if (pair) {
+        HGV_REQUIRE(act_bits && stat_partial && pair->C2 && pair->bits2 && pair->partial2 && hgv_aligned(pair->C2, 16) && !bwd && !gate,
+                    HGV_EINVAL, "gemm_nt16h_act2_stats: null / misaligned second output, keep bits or partial buffer");
+        HGV_REQUIRE(plan.ok, HGV_EUNSUPPORTED, "gemm_nt16h_act2_stats: (%d + %d) -> %d is not the shape of the two-draw store", K1, K2, N);
+        a.C2 = pair->C2; a.act_bits2 = pair->bits2; a.stat_partial2 = pair->partial2;
+    }
     if (bwd) {
         HGV_REQUIRE(!act_bits && !bias && !gate && ntr_bwd_shape(a.g, plan, A2 != nullptr), HGV_EUNSUPPORTED,
                     "gemm_nt16h_bwd: shape (%d + %d) -> %d is not one of the fused ones", K1, K2, N);
@@ -1492,6 +1528,29 @@ extern "C" int hgv_gemm_nt16h_bwd(const float* A1, int64_t lda1, int K1, const f
     const float scale = 1.0f / (float)(1.0 - (double)p);          // as the level's own kernels form it
     return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, nullptr, M, N, dy, lddy, nullptr, 0, stream, nullptr, 0, relu ? 1 : 0, scale,
                           nullptr, &b);
+}
+
+// hgv_gemm_nt16h_act_stats for two dropout draws of the one product: C / stat_partial take the draw of keep_bits, C2 /
+// stat_partial2 the draw of keep_bits2 (same leading dimensions; hgv_gemm_nt16h_act2_parts(M) parts each).  Built for the
+// first convolution of the two encode passes: two sources of 97...112 columns each, 129...144 outputs
+// (hgv_gemm_nt16h_act2_supported).
+extern "C" int hgv_gemm_nt16h_act2_parts(int64_t M) { return (int)ntr_grid(M < 1 ? 1 : M); }
+
+extern "C" int hgv_gemm_nt16h_act2_supported(int64_t M, int N, int K1, int K2) {
+    GeoH g;
+    if (!(M > 1 && N > 0 && K1 > 0 && K2 > 0 && geo_h(N, K1, K2, &g)) || g.stream) return 0;
+    return ntr_plan(g, M, true, true, true).ok ? 1 : 0;
+}
+
+extern "C" int hgv_gemm_nt16h_act2_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                                         const float* bias, int64_t M, int N, float* C, float* C2, int64_t ldc,
+                                         const uint32_t* keep_bits, const uint32_t* keep_bits2, int64_t ld_bits, int relu, float scale,
+                                         float* stat_partial, float* stat_partial2, hipStream_t stream) {
+    HGV_REQUIRE(M >= 2, HGV_EINVAL, "gemm_nt16h_act2_stats: statistics need at least two rows");
+    HGV_REQUIRE(A2 != nullptr && keep_bits && stat_partial, HGV_EINVAL, "gemm_nt16h_act2_stats: two sources, keep bits and partial buffers expected");
+    const NtHPair pr{C2, keep_bits2, stat_partial2};
+    return gemm_nt16h_any(A1, lda1, K1, A2, lda2, K2, Wp, bias, M, N, C, ldc, nullptr, 0, stream, keep_bits, ld_bits, relu ? 1 : 0, scale,
+                          stat_partial, nullptr, &pr);
 }
 
 // hgv_gemm_nt16h that does its work only when (*gate != 0) == run_if_set (gate: device int written earlier on the

@@ -499,21 +499,30 @@ class _BnStatsPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, relu, p, seed, offset, offset2, ctr, eps, momentum, tracked,
-                parts_a, parts_b):
+                parts_a, parts_b, pre=None):
         n, h = y.shape
         if n < 2:
             raise ValueError("Expected more than 1 value per channel when training")
         lib = _lib.load()
-        ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
         hp = (h + 3) // 4 * 4
         st = torch.empty(2, 2, hp, dtype=torch.float32, device=y.device)            # [s | t][draw][hp]
         stats = torch.empty(2, 2, h, dtype=torch.float32, device=y.device)          # [mean | rstd][draw][h]
         d1 = y.detach()
-        d2 = torch.empty_strided((n, h), (ld_of(y), 1), dtype=torch.float32, device=y.device)
-        _lib.call("hgv_bn_stats_act2", d1.data_ptr(), d2.data_ptr(), ld_of(d1), n, h, int(relu), float(p), seed, offset, offset2,
-                  ctr, _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
-                  float(momentum), _lib.ptr(tracked), stats[0].data_ptr(), stats[1].data_ptr(), st[0].data_ptr(),
-                  st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        if pre is not None:
+            # the producing projection has stored both draws (the first in y's place) and left their partial column statistics:
+            # the two merges update the running statistics in the order of the draws
+            partial, d2 = pre
+            for k in range(2):
+                _lib.call("hgv_bn_stats_merge", partial[k].data_ptr(), partial.size(1), 16, n, h, _lib.ptr(gamma), _lib.ptr(beta),
+                          float(eps), _lib.ptr(running_mean), _lib.ptr(running_var), float(momentum), _lib.ptr(tracked),
+                          stats[0, k].data_ptr(), stats[1, k].data_ptr(), st[0, k].data_ptr(), st[1, k].data_ptr(), _lib.stream())
+        else:
+            ws = _workspace(lib.hgv_bn_act_ws(n, h), y.device, "bn")
+            d2 = torch.empty_strided((n, h), (ld_of(y), 1), dtype=torch.float32, device=y.device)
+            _lib.call("hgv_bn_stats_act2", d1.data_ptr(), d2.data_ptr(), ld_of(d1), n, h, int(relu), float(p), seed, offset, offset2,
+                      ctr, _lib.ptr(gamma), _lib.ptr(beta), float(eps), _lib.ptr(running_mean), _lib.ptr(running_var),
+                      float(momentum), _lib.ptr(tracked), stats[0].data_ptr(), stats[1].data_ptr(), st[0].data_ptr(),
+                      st[1].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.cfg = (bool(relu), float(p))
         ctx.parts = (parts_a, parts_b)
         ctx.save_for_backward(d1, d2, gamma, stats, beta)
@@ -530,7 +539,7 @@ class _BnStatsPair(torch.autograd.Function):
         if h is None:
             h, h2 = h2, None
         if g is None and h is None:
-            return (None,) * 16
+            return (None,) * 17
         n, hh = d1.shape
         lib = _lib.load()
         ws = _workspace(lib.hgv_bn_act_ws(n, hh), d1.device, "bn")
@@ -588,30 +597,65 @@ class _BnStatsPair(torch.autograd.Function):
                 parts.parts.clear()
         if direct:
             dgamma = dbeta = None
-        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 13
+        return (dy, dgamma if need[1] else None, dbeta if need[2] else None) + (None,) * 14
 
 
-def bn_level_pair(y: torch.Tensor, bn: torch.nn.BatchNorm1d, relu: bool, p: float):
+_pair_in_product = os.environ.get("HGVAE_PAIR_IN_PRODUCT", "1") != "0"    # 0: the two-draw level reads the pre-activation in a pass of its own (A/B)
+
+
+def bn_level_pair(y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, rows: Optional[int] = None):
     """Training-mode relu? -> Dropout(p) -> BatchNorm1d for two successive dropout draws of the same fresh matrix ``y``
     (the two encode passes of a train step over the shared first convolution), each result as a pair of handles for its
     two consumers: ``((a, a'), (b, b'))`` - :class:`Deferred` levels inside :func:`deferred_levels`, else tensors
     (:func:`bn_act_pair`) - or None when neither form applies (explicit noise tapes, p = 0, unaligned rows, no gradient)
-    and the caller makes two ordinary calls."""
+    and the caller makes two ordinary calls.
+
+    ``y`` may be a callable that builds the matrix with exactly one projection operator of this module (and ``rows`` its
+    row count): the product may then store both draws and their column sums itself, and the result is ``(pair or None,
+    y)``."""
+    global _act_request, _act_done, _act_ready
+    made = callable(y)
+    pre = None
+    if made:
+        make = y
+        ask = (_defer and _defer_pair and _pair_in_product and _nt_act and _nt_stats and torch.is_grad_enabled() and p >= DEFER_MIN_P
+               and (rows is None or rows >= max(2, DEFER_MIN_ROWS)) and noise_is_counter_based() and not on_branch_stream())
+        _act_done = None
+        _act_request = (relu, p, "pair") if ask else None
+        try:
+            y = plain(make())
+        finally:
+            _act_request = None
+            _act_ready = None
+        done, _act_done = _act_done, None
+        if done is not None:
+            if done[:5] != (y.data_ptr(), y.size(0), y.size(1), relu, p) or len(done) < 7:
+                raise _lib.HgvError("a projection stored two activated draws that are not this level's input")
+            pre = done
     if _defer and _defer_pair and torch.is_grad_enabled() and p >= DEFER_MIN_P and y.dim() == 2 \
             and y.size(0) >= max(2, DEFER_MIN_ROWS) and y.requires_grad and y.grad_fn is not None and is_vec4(y) \
             and y.size(1) <= 512 and noise_is_counter_based() and not on_branch_stream():
-        noise = current_noise()
-        _, seed, offset, ctr = noise.dropout(y.shape, y.device)
-        _, _, offset2, _ = noise.dropout(y.shape, y.device)
+        if pre is not None:
+            out2, seed, offset, offset2, ctr = pre[6]
+            stored = (pre[5], out2)
+        else:
+            noise = current_noise()
+            _, seed, offset, ctr = noise.dropout(y.shape, y.device)
+            _, _, offset2, _ = noise.dropout(y.shape, y.device)
+            stored = None
         momentum = bn.momentum if bn.momentum is not None else 0.1
         pa, pb = _GradParts(), _GradParts()
         a, a2, b, b2, st, stats = _BnStatsPair.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, relu, p, seed, offset,
-                                                     offset2, ctr, bn.eps, momentum, bn.num_batches_tracked, pa, pb)
+                                                     offset2, ctr, bn.eps, momentum, bn.num_batches_tracked, pa, pb, stored)
 
         def wrap(h, k, parts):
             return Deferred(h, st[0, k], st[1, k], stats[0, k], stats[1, k], bn.weight, bn.bias, parts)
-        return (wrap(a, 0, pa), wrap(a2, 0, pa)), (wrap(b, 1, pb), wrap(b2, 1, pb))
-    return bn_act_pair(y, bn, relu, p)
+        pair = (wrap(a, 0, pa), wrap(a2, 0, pa)), (wrap(b, 1, pb), wrap(b2, 1, pb))
+        return (pair, y) if made else pair
+    if pre is not None:
+        raise _lib.HgvError("a projection stored two activated draws for a level that cannot take them")
+    pair = bn_act_pair(y, bn, relu, p)
+    return (pair, y) if made else pair
 
 
 def bn_level(make_y, bn: torch.nn.BatchNorm1d, relu: bool, p: float, training: bool, fork: bool = False, act_ok: bool = False,
@@ -957,14 +1001,25 @@ _nt_stats = os.environ.get("HGVAE_NT_STATS", "1") != "0"        # 0: a pass of i
 
 
 def _take_act(m: int, n_out: int, k1: int, k2: int, kind: str, device):
-    """(relu, p, scale, bits, seed/offset record) for a projection that stores the activated level, or None."""
+    """(relu, p, mask, seed, offset, counter, second draw) for a projection that stores the activated level, or None.  A
+    request for two draws (``bn_level_pair``) is met with both, taken in order: second draw = (mask, offset)."""
     global _act_request
     req, _act_request = _act_request, None
-    if req is None or kind != "f16x3" or m < max(2, DEFER_MIN_ROWS) or not _lib.load().hgv_gemm_nt16h_act_supported(n_out, k1, k2):
+    if req is None or kind != "f16x3" or m < max(2, DEFER_MIN_ROWS):
+        return None
+    lib = _lib.load()
+    if len(req) == 3:
+        if not lib.hgv_gemm_nt16h_act2_supported(m, n_out, k1, k2):
+            return None
+        relu, p, _ = req
+        mask, seed, offset, ctr = current_noise().dropout((m, n_out), device)
+        mask2, _, offset2, _ = current_noise().dropout((m, n_out), device)
+        return relu, p, mask, seed, offset, ctr, (mask2, offset2)
+    if not lib.hgv_gemm_nt16h_act_supported(n_out, k1, k2):
         return None
     relu, p = req
     mask, seed, offset, ctr = current_noise().dropout((m, n_out), device)
-    return relu, p, mask, seed, offset, ctr
+    return relu, p, mask, seed, offset, ctr, None
 
 
 _act_ready = None            # keep bits of a pending activated store, already being generated on the side stream
@@ -990,18 +1045,25 @@ def _start_level_bits(m: int, n_out: int, k1: int, k2: int, device) -> None:
     act = _take_act(m, n_out, k1, k2, "f16x3", device)
     if act is None:
         return
-    relu, p, mask, seed, offset, ctr = act
+    relu, p, mask, seed, offset, ctr, second = act
     words = ((n_out + 3) // 4 * 4 + 31) // 32
     bits = torch.empty((m, words), dtype=torch.int32, device=device)
+    bits2 = torch.empty((m, words), dtype=torch.int32, device=device) if second is not None else None
     main, side = torch.cuda.current_stream(device), _side_stream(device)
     side.wait_stream(main)                 # the buffer may be a recycled block whose last use is still queued on the main stream
-    if mask is not None:
-        mask.record_stream(side)           # an explicit mask lives until the side stream has read it
+    for t in (mask, second[0] if second is not None else None):
+        if t is not None:
+            t.record_stream(side)          # an explicit mask lives until the side stream has read it
     with torch.cuda.stream(side):
         _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+        if second is not None:
+            _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(second[0]), seed, second[1], ctr, bits2.data_ptr(), words,
+                      _lib.stream())
         done = side.record_event()
     bits.record_stream(side)
-    _act_ready = (m, n_out, relu, p, bits, words, done)
+    if bits2 is not None:
+        bits2.record_stream(side)
+    _act_ready = (m, n_out, relu, p, bits, words, done, (bits2, seed, offset, second[1], ctr) if second is not None else None)
 
 
 _act_queue: list = []        # keep bits of the NEXT levels, in the order their products will ask for them (start_bits_ahead)
@@ -1035,7 +1097,7 @@ def start_bits_ahead(levels, training: bool, device) -> None:
             _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
             done = side.record_event()
         bits.record_stream(side)
-        _act_queue.append((m, n_out, bool(relu), float(p), bits, words, done))
+        _act_queue.append((m, n_out, bool(relu), float(p), bits, words, done, None))
 
 
 def drop_bits_ahead() -> None:
@@ -1065,15 +1127,35 @@ def _gemm_nt(xa, img: _Image, xb, bias, n_out: int, level_out: bool = False) -> 
         raise _lib.HgvError("keep bits were prepared for another product")
     if ready is not None or act is not None:
         if ready is not None:
-            _, _, relu, p, bits, words, done = ready
+            _, _, relu, p, bits, words, done, two = ready
             torch.cuda.current_stream(xa.device).wait_event(done)
         else:
-            relu, p, mask, seed, offset, ctr = act
+            relu, p, mask, seed, offset, ctr, second = act
             words = (ld_of(out) + 31) // 32
             bits = torch.empty((m, words), dtype=torch.int32, device=xa.device)
             _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(mask), seed, offset, ctr, bits.data_ptr(), words, _lib.stream())
+            two = None
+            if second is not None:
+                bits2 = torch.empty((m, words), dtype=torch.int32, device=xa.device)
+                _lib.call("hgv_dropout_bits", m, n_out, float(p), _lib.ptr(second[0]), seed, second[1], ctr, bits2.data_ptr(), words,
+                          _lib.stream())
+                two = (bits2, seed, offset, second[1], ctr)
         if ev:
             ev[0].record()
+        if two is not None:
+            # two dropout draws of this product: both activated matrices and both sets of column sums in one pass
+            bits2, seed, offset, offset2, ctr = two
+            out2 = new_padded(m, n_out, xa.device, zero_pad=False)
+            nparts = _lib.load().hgv_gemm_nt16h_act2_parts(m)
+            partial = torch.empty((2, nparts, 2, ld_of(out)), dtype=torch.float32, device=xa.device)
+            _lib.call("hgv_gemm_nt16h_act2_stats", xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
+                      xb.size(1) if xb is not None else 0, img.a.data_ptr(), _lib.ptr(bias), m, n_out, out.data_ptr(), out2.data_ptr(),
+                      ld_of(out), bits.data_ptr(), bits2.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)), partial[0].data_ptr(),
+                      partial[1].data_ptr(), _lib.stream())
+            if ev:
+                ev[1].record()
+            _act_done = (out.data_ptr(), m, n_out, relu, p, partial, (out2, seed, offset, offset2, ctr))
+            return out
         common = (xa.data_ptr(), ld_of(xa), xa.size(1), _lib.ptr(xb), ld_of(xb) if xb is not None else 0,
                   xb.size(1) if xb is not None else 0, img.a.data_ptr(), _lib.ptr(bias), m, n_out, out.data_ptr(), ld_of(out),
                   bits.data_ptr(), words, int(relu), 1.0 / (1.0 - float(p)))

@@ -150,8 +150,13 @@ class SkipconVAE(_VAEBase):
             kind, kept = memo[3]
             memo.clear()
             return kept if kind == "levels" else self._finish(kept, drop, bn, relu=True, fork=True)
-        y = conv(x, g)
-        pair = Fn.bn_level_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
+        if self.training and Fn.noise_is_counter_based() and type(conv) is SAGEConv:
+            # a SAGEConv is one projection operator (see _sage_level): handed over as a callable, its product may store both
+            # draws of the level itself
+            pair, y = Fn.bn_level_pair(lambda: conv(x, g), bn, True, drop.p, rows=x.size(0))
+        else:
+            y = conv(x, g)
+            pair = Fn.bn_level_pair(y, bn, True, drop.p) if self.training and Fn.noise_is_counter_based() else None
         if pair is not None:
             done = None
             if _two_streams(y.size(0)):  # the second pass may start here, next to the rest of the first

@@ -496,6 +496,16 @@ int hgv_gemm_nt16h_act_parts(int64_t M, int N, int K1, int K2);
 int hgv_gemm_nt16h_act_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                              const float* bias, int64_t M, int N, float* C, int64_t ldc, const uint32_t* keep_bits,
                              int64_t ld_bits, int relu, float scale, float* stat_partial, hgv_stream_t stream);
+/* hgv_gemm_nt16h_act_stats for TWO dropout draws of the one product - the first level of the reference's two encode passes
+ * shares one pre-activation (gvae/gvae_skipcon.py:166-171): C / stat_partial take the draw of keep_bits, C2 / stat_partial2
+ * the draw of keep_bits2 (same leading dimensions; hgv_gemm_nt16h_act2_parts(M) parts each).  Two sources of 97...112 columns
+ * each, 129...144 outputs (hgv_gemm_nt16h_act2_supported). */
+int hgv_gemm_nt16h_act2_supported(int64_t M, int N, int K1, int K2);
+int hgv_gemm_nt16h_act2_parts(int64_t M);
+int hgv_gemm_nt16h_act2_stats(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
+                              const float* bias, int64_t M, int N, float* C, float* C2, int64_t ldc, const uint32_t* keep_bits,
+                              const uint32_t* keep_bits2, int64_t ld_bits, int relu, float scale, float* stat_partial,
+                              float* stat_partial2, hgv_stream_t stream);
 int hgv_gemm_nt16_gated(const float* A1, int64_t lda1, int K1, const float* A2, int64_t lda2, int K2, const void* Wp,
                         const float* bias, int64_t M, int N, float* C, int64_t ldc, const int* gate, int run_if_set,
                         hgv_stream_t stream);

@@ -169,6 +169,58 @@ def test_two_draws_of_one_pre_activation_as_two_deferred_levels(n, h, which):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,f_in,n_out", [(3001, 105, 138), (40_007, 105, 138), (50_001, 100, 129), (5000, 60, 138), (120, 105, 138),
+                                          (7, 105, 138)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_projection_stores_both_draws_of_a_shared_level(n, f_in, n_out, relu, monkeypatch):
+    """hgv_gemm_nt16h_act2_stats (+ two hgv_dropout_bits, two hgv_bn_stats_merge) against the projection followed by
+    hgv_bn_stats_act2: both stored matrices are the same bits (signed zeros included), the statistics, s / t and the running
+    buffers agree to rounding, every gradient likewise; source widths outside 97...112 keep the pass of their own."""
+    from hgvae_amd import functional as Fn
+    from hgvae_amd.graph import graph_of
+    from hgvae_amd.noise import PhiloxNoise, use_noise
+    gen = torch.Generator(device=dev()).manual_seed(n + n_out)
+    ei, _, _ = path_batch([n])
+    ei = torch.cat([ei, torch.randint(0, n, (2, 4000))], 1).to(dev())
+    graph = graph_of(ei, n)
+    x0 = _rand((n, f_in), gen)
+    w1, w2, bias = _rand((n_out, f_in), gen, 0.1), _rand((n_out, f_in), gen, 0.1), _rand((n_out,), gen, 0.1)
+    gs = [_rand((n, n_out), gen) for _ in range(4)]
+    results = []
+    for in_product in (True, False):
+        monkeypatch.setattr(Fn, "_pair_in_product", in_product)
+        bn = _bn(n_out, torch.Generator(device=dev()).manual_seed(5))
+        x = x0.clone().requires_grad_(True)
+        wa, wb, b = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        monkeypatch.setattr(Fn._lib, "call", spy_call)
+        with use_noise(PhiloxNoise(4321)), Fn.deferred_levels():
+            pair, y = Fn.bn_level_pair(lambda: Fn.sage_conv(x, graph, wa, b, wb, mean=True), bn, relu, 0.5, rows=n)
+        monkeypatch.setattr(Fn._lib, "call", real_call)
+        covered = f_in > 96
+        assert ("hgv_gemm_nt16h_act2_stats" in names) == (in_product and covered), names
+        assert ("hgv_bn_stats_act2" in names) == (not (in_product and covered)), names
+        assert names.count("hgv_dropout_bits") == (2 if in_product and covered else 0)
+        levels = [t for draw in pair for t in draw]
+        assert all(isinstance(t, Fn.Deferred) for t in levels)
+        ds = [levels[0].d.detach().clone(), levels[2].d.detach().clone()]
+        torch.autograd.backward([t.tensor() for t in levels], gs)
+        results.append((ds, [levels[0].s.clone(), levels[0].t.clone(), levels[2].s.clone(), levels[2].t.clone(), bn.running_mean.clone(),
+                             bn.running_var.clone(), bn.weight.grad.clone(), bn.bias.grad.clone(), x.grad.clone(), wa.grad.clone(),
+                             wb.grad.clone(), b.grad.clone()], int(bn.num_batches_tracked)))
+    (da, va, ta), (db, vb, tb) = results
+    assert ta == tb == 2
+    for u, v in zip(da, db):
+        assert torch.equal(u.view(torch.int32), v.view(torch.int32))
+    for u, v in zip(va, vb):
+        assert float((u.double() - v.double()).abs().max()) <= 3e-6 * max(float(v.abs().max()), 1e-30), (float((u - v).abs().max()), float(v.abs().max()))
+
+
 @pytest.mark.parametrize("op,relu,n_out", [("sage", True, 138), ("concat", False, 138), ("dual", True, 144), ("dual", False, 129),
                                            ("sage", True, 64), ("concat", True, 160)])
 @pytest.mark.parametrize("in_product_stats", [False, True])
@@ -489,7 +541,8 @@ def test_step_is_the_same_bits_with_and_without_the_overlaps_and_fusions(monkeyp
         # fused: the three decoder levels, the third encoder level of both passes and the second level of both (in the first
         # pass it also feeds a skip connection: the product that runs last adds the other's share)
         assert names.count("hgv_gemm_nt16h_bwd") == (7 if fuse else 0), names.count("hgv_gemm_nt16h_bwd")
-        assert names.count("hgv_dropout_bits") == 7
+        assert names.count("hgv_dropout_bits") == 9          # seven levels, the first one shared by the passes with two draws
+        assert names.count("hgv_gemm_nt16h_act2_stats") == 1
         assert not Fn._act_queue
         results.append((loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
                         {k: b.clone() for k, b in model.named_buffers()}))
