@@ -142,6 +142,8 @@ SIGNATURES = {
     "hgv_kl_bwd": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _i32, _vp]),
     "hgv_mse_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
     "hgv_mse_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "hgv_mse_fwd_grad": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp]),
+    "hgv_mse_bwd_unless_unit": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

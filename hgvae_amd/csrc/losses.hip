@@ -150,12 +150,15 @@ __global__ __launch_bounds__(256) void k_kl_partial(const float* __restrict__ ml
     block_reduce_store(acc, partial);
 }
 
-template <bool VEC>
+// GRAD: the same pass also writes the gradient for a unit upstream gradient, gr = 2 / (N F) * (r - x) - the values k_mse_bwd
+// writes for *gout == 1 (same expression, same bits)
+template <bool VEC, bool GRAD = false>
 __global__ __launch_bounds__(256) void k_mse_partial(const float* __restrict__ r, int64_t ldr,
                                                      const float* __restrict__ x, int64_t ldx, int64_t N, int F, int ct,
-                                                     float* __restrict__ partial) {
+                                                     float* __restrict__ partial, float* __restrict__ gr = nullptr, int64_t ldg = 0) {
     const Walk w(F, ct);
     float acc = 0.f;
+    const float s = 2.0f * 1.0f / ((float)N * (float)F);
     for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
         for (int c = w.c; c < w.CH; c += ct) {
             float4 a = ldc<VEC>(r + row * ldr, 4 * c, F), b = ldc<VEC>(x + row * ldx, 4 * c, F);
@@ -164,6 +167,7 @@ __global__ __launch_bounds__(256) void k_mse_partial(const float* __restrict__ r
                 const float d = el(a, e) - el(b, e);
                 if (4 * c + e < F) acc += d * d;
             }
+            if (GRAD) stc<VEC>(gr + row * ldg, 4 * c, F, make_float4(s * (a.x - b.x), s * (a.y - b.y), s * (a.z - b.z), s * (a.w - b.w)));
         }
     }
     block_reduce_store(acc, partial);
@@ -213,8 +217,9 @@ __global__ __launch_bounds__(256) void k_kl_bwd(const float* __restrict__ ml, in
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_mse_bwd(const float* __restrict__ r, int64_t ldr, const float* __restrict__ x,
                                                  int64_t ldx, int64_t N, int F, int ct, const float* __restrict__ gout,
-                                                 float* __restrict__ gr, int64_t ldg) {
+                                                 float* __restrict__ gr, int64_t ldg, int unless_unit = 0) {
     const Walk w(F, ct);
+    if (unless_unit && gout[0] == 1.0f) return;          // gr already holds the gradient for a unit upstream gradient (k_mse_partial<., true>)
     const float s = 2.0f * gout[0] / ((float)N * (float)F);
     for (int64_t row = (int64_t)blockIdx.x * w.RS + w.slot; row < N; row += (int64_t)gridDim.x * w.RS) {
         for (int c = w.c; c < w.CH; c += ct) {
@@ -323,5 +328,35 @@ extern "C" int hgv_mse_bwd(const float* r, int64_t ldr, const float* x, int64_t 
         hipLaunchKernelGGL(k_mse_bwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg);
     else hipLaunchKernelGGL(k_mse_bwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg);
     HGV_CHECK_LAUNCH("mse_bwd");
+    return HGV_OK;
+}
+
+// hgv_mse_fwd that also writes the gradient with respect to r for an upstream gradient of exactly 1 - gr = 2 / (N F) (r - x),
+// what hgv_mse_bwd writes for *gout == 1 - in the same pass over r and x: a loss that enters the total with weight one (the
+// reference adds recon_loss + kl, gvae/gvae_skipcon.py:174-176) then needs no second pass.  hgv_mse_bwd_unless_unit is that
+// second pass for any other upstream gradient: it rewrites gr as hgv_mse_bwd does when *gout != 1 and returns at once otherwise
+// (the decision is taken on the device: no host round trip).
+extern "C" int hgv_mse_fwd_grad(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, float* out, float* gr,
+                                int64_t ldg, void* ws, size_t ws_bytes, hipStream_t stream) {
+    HGV_REQUIRE(N > 0 && F > 0 && r && x && out && gr && ws && ldr >= F && ldx >= F && ldg >= F, HGV_EINVAL, "mse_fwd_grad: bad arguments");
+    HGV_REQUIRE(ws_bytes >= hgv_loss_ws(), HGV_EWORKSPACE, "mse_fwd_grad: workspace too small");
+    const int ct = ct_for(F);
+    const int g = grid_rows(N, ct);
+    if (rows_vec(r, ldr, F) && rows_vec(x, ldx, F) && rows_vec(gr, ldg, F))
+        hipLaunchKernelGGL((k_mse_partial<true, true>), dim3(g), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, (float*)ws, gr, ldg);
+    else hipLaunchKernelGGL((k_mse_partial<false, true>), dim3(g), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, (float*)ws, gr, ldg);
+    hipLaunchKernelGGL(k_finish_sum, dim3(1), dim3(256), 0, stream, (const float*)ws, g, 1.0 / ((double)N * (double)F), out);
+    HGV_CHECK_LAUNCH("mse_fwd_grad");
+    return HGV_OK;
+}
+
+extern "C" int hgv_mse_bwd_unless_unit(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F,
+                                       const float* gout, float* gr, int64_t ldg, hipStream_t stream) {
+    HGV_REQUIRE(N > 0 && F > 0 && r && x && gout && gr && ldr >= F && ldx >= F && ldg >= F, HGV_EINVAL, "mse_bwd_unless_unit: bad arguments");
+    const int ct = ct_for(F);
+    if (rows_vec(r, ldr, F) && rows_vec(x, ldx, F) && rows_vec(gr, ldg, F))
+        hipLaunchKernelGGL(k_mse_bwd<true>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg, 1);
+    else hipLaunchKernelGGL(k_mse_bwd<false>, dim3(grid_rows(N, ct)), dim3(256), 0, stream, r, ldr, x, ldx, N, F, ct, gout, gr, ldg, 1);
+    HGV_CHECK_LAUNCH("mse_bwd_unless_unit");
     return HGV_OK;
 }

@@ -2119,14 +2119,27 @@ def kl_divergence(ml: torch.Tensor, z_dim: int) -> torch.Tensor:
     return _KL.apply(ml, z_dim)
 
 
+_mse_early = os.environ.get("HGVAE_MSE_EARLY", "1") != "0"      # 0: the gradient of the mean squared error is formed in the backward pass (A/B)
+
+
 class _MSE(torch.autograd.Function):
+    """mean((r - x)^2).  When r needs a gradient the forward pass writes it as well, for an upstream gradient of one (the
+    loss enters the total with weight one, gvae/gvae_skipcon.py:176): the pass reads r and x anyway, and the backward pass
+    then only has to look at the upstream gradient on the device - a second pass over r and x runs when it is not 1."""
+
     @staticmethod
     def forward(ctx, r, x):
         r, x = rowmajor(r), rowmajor(x)
         out = torch.empty((), dtype=torch.float32, device=r.device)
         ws = _workspace(_lib.load().hgv_loss_ws(), r.device, "loss")
-        _lib.call("hgv_mse_fwd", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1),
-                  out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
+        ctx.gr, ctx.calls = None, 0
+        if _mse_early and ctx.needs_input_grad[0] and r.size(0) >= max(2, DEFER_MIN_ROWS):
+            ctx.gr = new_padded(r.size(0), r.size(1), r.device)
+            _lib.call("hgv_mse_fwd_grad", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1), out.data_ptr(),
+                      ctx.gr.data_ptr(), ld_of(ctx.gr), ws.data_ptr(), ws.numel(), _lib.stream())
+        else:
+            _lib.call("hgv_mse_fwd", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1),
+                      out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
         ctx.save_for_backward(r, x)
         return out
 
@@ -2134,9 +2147,16 @@ class _MSE(torch.autograd.Function):
     def backward(ctx, g):
         r, x = ctx.saved_tensors
         g = g.contiguous().to(torch.float32)
-        gr = new_padded(r.size(0), r.size(1), r.device)
-        _lib.call("hgv_mse_bwd", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1), g.data_ptr(),
-                  gr.data_ptr(), ld_of(gr), _lib.stream())
+        first = ctx.gr is not None and ctx.calls == 0
+        ctx.calls += 1
+        if first:
+            gr = ctx.gr          # holds the gradient for g == 1; rewritten on the device when g is anything else
+            _lib.call("hgv_mse_bwd_unless_unit", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1), g.data_ptr(),
+                      gr.data_ptr(), ld_of(gr), _lib.stream())
+        else:
+            gr = new_padded(r.size(0), r.size(1), r.device)
+            _lib.call("hgv_mse_bwd", r.data_ptr(), ld_of(r), x.data_ptr(), ld_of(x), r.size(0), r.size(1), g.data_ptr(),
+                      gr.data_ptr(), ld_of(gr), _lib.stream())
         # the target's gradient is the negative of the reconstruction's (only asked for when the input itself needs one)
         return (gr if ctx.needs_input_grad[0] else None), (-gr if ctx.needs_input_grad[1] else None)
 

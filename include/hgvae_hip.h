@@ -194,6 +194,14 @@ int hgv_mse_fwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_
                 size_t ws_bytes, hgv_stream_t stream);
 int hgv_mse_bwd(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, const float* gout,
                 float* gr, int64_t ldg, hgv_stream_t stream);
+/* F.mse_loss (gvae/gvae_skipcon.py:174) with its gradient written by the forward pass: hgv_mse_fwd_grad is hgv_mse_fwd that
+ * also writes gr = 2 / (N F) (r - x), the gradient for an upstream gradient of exactly 1 (the reference adds the loss terms with
+ * weight one, :176); hgv_mse_bwd_unless_unit rewrites gr as hgv_mse_bwd does when *gout != 1 and returns at once when it is 1
+ * (decided on the device). */
+int hgv_mse_fwd_grad(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, float* out, float* gr,
+                     int64_t ldg, void* ws, size_t ws_bytes, hgv_stream_t stream);
+int hgv_mse_bwd_unless_unit(const float* r, int64_t ldr, const float* x, int64_t ldx, int64_t N, int F, const float* gout,
+                            float* gr, int64_t ldg, hgv_stream_t stream);
 
 /* Exclusive prefix sum of int32 (in and out may alias). */
 size_t hgv_exclusive_scan_ws(int64_t n);

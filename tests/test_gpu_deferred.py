@@ -425,6 +425,44 @@ def test_sage_convolution_on_a_deferred_operand(first, h_in):
         assert float((a - b).abs().max()) <= 2e-5 * scale, (what, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("n,f", [(5000, 105), (333, 7), (40_001, 60)])
+@pytest.mark.parametrize("weight", [1.0, 0.7, -2.0])
+def test_mse_gradient_written_by_the_forward_pass(n, f, weight, monkeypatch):
+    """hgv_mse_fwd_grad + hgv_mse_bwd_unless_unit against hgv_mse_fwd + hgv_mse_bwd: same loss and the same gradient bits
+    whether the loss enters the total with weight one (the forward pass has written the gradient, the backward pass only
+    looks at the weight) or with another weight (the backward pass rewrites it) - also on a second backward pass over the
+    same graph."""
+    from hgvae_amd import functional as Fn
+    gen = torch.Generator(device=dev()).manual_seed(n + f)
+    r0, x = _rand((n, f), gen), _rand((n, f), gen)
+    res = []
+    for early in (True, False):
+        monkeypatch.setattr(Fn, "_mse_early", early)
+        names = []
+        real_call = Fn._lib.call
+
+        def spy_call(name, *a, _names=names, _real=real_call):
+            _names.append(name)
+            return _real(name, *a)
+        monkeypatch.setattr(Fn._lib, "call", spy_call)
+        r = r0.clone().requires_grad_(True)
+        loss = Fn.mse_loss(Fn.as_padded(r), x)
+        total = loss * weight if weight != 1.0 else loss + 0.0
+        total.backward(retain_graph=True)
+        g1 = r.grad.clone()
+        r.grad = None
+        (loss * 3.0).backward()
+        monkeypatch.setattr(Fn._lib, "call", real_call)
+        assert ("hgv_mse_fwd_grad" in names) == early and ("hgv_mse_bwd_unless_unit" in names) == early
+        res.append((loss.detach().clone(), g1, r.grad.clone()))
+    for u, v in zip(res[0], res[1]):
+        assert torch.equal(u, v)
+    ref = torch.nn.functional.mse_loss(r0.double(), x.double())
+    assert abs(float(res[0][0]) - float(ref)) <= 1e-6 * float(ref)
+    want = 2.0 * weight * (r0.double() - x.double()) / (n * f)
+    assert float((res[0][1].double() - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
 @pytest.mark.parametrize("variant", ["skipcon", "attention", "pool", "custom_pool"])
 def test_train_step_with_deferred_levels_matches_the_plain_path(variant):
     """One reference train step with explicit noise: deferral on against deferral off - loss, every gradient, the
