@@ -66,6 +66,16 @@ __device__ __forceinline__ void st4(float* base, int64_t ld, int64_t row, int c0
     }
 }
 
+// A dropout rate that is a multiple of 1 / 256 (the reference's 0.5 is) needs one byte of the generator per decision instead of
+// sixteen bits: one call then serves TWO chunk pairs - call q of a row gives pair 2q the bytes of its words x (chunk 2q) and y
+// (chunk 2q + CP), pair 2q + 1 those of z and w.  Kernels whose threads own one pair gain nothing (each thread makes the call of
+// its pair's even partner); the kernel that only packs decisions into bits makes half the calls.
+__device__ __forceinline__ bool keep_by_bytes(const EpArgs& a) { return (a.thresh & 0xffu) == 0u; }
+__device__ __forceinline__ uint4 keep_bytes16(const EpArgs& a, const HgvPhilox& ph, int64_t row, int q, uint64_t off) {
+    return ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)q << 8) ^ 0x40000000u, (uint32_t)off,
+                        (uint32_t)(off >> 32));
+}
+
 // keep-multipliers (0 or scale) for the two 4-column chunks (cp, cp + CP) of chunk pair cp
 __device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, float4 (&k)[2], int set = 0) {
     k[0] = k[1] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -82,6 +92,16 @@ __device__ __forceinline__ void keep8(const EpArgs& a, int64_t row, int cp, floa
     } else if (a.mode == 2) {
         const HgvPhilox ph(a.seed);
         const uint64_t off = (set ? a.offset2 : a.offset) + (a.offset_dev ? a.offset_dev[0] : 0ull);
+        if (keep_by_bytes(a)) {
+            // one byte per decision: the call of the pair's even partner serves both pairs (see keep_bytes16)
+            const uint4 r = keep_bytes16(a, ph, row, cp >> 1, off);
+            const uint32_t T8 = a.thresh >> 8, w0 = (cp & 1) ? r.z : r.x, w1 = (cp & 1) ? r.w : r.y;
+            k[0].x = (w0 & 0xffu) >= T8 ? a.scale : 0.f; k[0].y = ((w0 >> 8) & 0xffu) >= T8 ? a.scale : 0.f;
+            k[0].z = ((w0 >> 16) & 0xffu) >= T8 ? a.scale : 0.f; k[0].w = (w0 >> 24) >= T8 ? a.scale : 0.f;
+            k[1].x = (w1 & 0xffu) >= T8 ? a.scale : 0.f; k[1].y = ((w1 >> 8) & 0xffu) >= T8 ? a.scale : 0.f;
+            k[1].z = ((w1 >> 16) & 0xffu) >= T8 ? a.scale : 0.f; k[1].w = (w1 >> 24) >= T8 ? a.scale : 0.f;
+            return;
+        }
         const uint4 r = ph.rounds<7>((uint32_t)row, (uint32_t)((uint64_t)row >> 32) ^ ((uint32_t)cp << 8),
                                      (uint32_t)off, (uint32_t)(off >> 32));
         const uint32_t T = a.thresh;
@@ -881,23 +901,50 @@ namespace {
 // Keep decisions of one dropout call as bits: bit c & 31 of bits[row * ldb + (c >> 5)] = 1 when element (row, c) is kept
 // (the decisions of keep8 with the same seed / offset; columns >= H read as kept).  The thread mapping is that of the
 // other kernels of this file (a thread owns the chunk pair cp, cp + CP of a row); the row's words are assembled in LDS.
-__global__ __launch_bounds__(256) void k_dropout_bits(const EpArgs a, uint32_t* __restrict__ bits, int64_t ldb, int W) {
-    __shared__ uint32_t sh[512];
+__device__ __forceinline__ uint32_t byte_nibble(uint32_t w, uint32_t T8) {
+    return ((w & 0xffu) >= T8 ? 1u : 0u) | (((w >> 8) & 0xffu) >= T8 ? 2u : 0u) | (((w >> 16) & 0xffu) >= T8 ? 4u : 0u) | ((w >> 24) >= T8 ? 8u : 0u);
+}
+
+// BYTES: the rate is a multiple of 1 / 256 and the noise comes from the generator: a thread owns TWO chunk pairs (2 q, 2 q + 1)
+// of a row and makes the one call that decides both (keep_bytes16); launched with RPB2 = 256 / ceil(CP / 2) rows per round.
+template <bool BYTES>
+__global__ __launch_bounds__(256) void k_dropout_bits(const EpArgs a, uint32_t* __restrict__ bits, int64_t ldb, int W, int RPB2) {
+    __shared__ uint32_t sh[1024];
     const int t = threadIdx.x;
-    const bool active = t < a.RPB * a.CP;
-    const int rsub = t / a.CP, cp = t - rsub * a.CP;
-    for (int64_t r0 = (int64_t)blockIdx.x * a.RPB; r0 < a.N; r0 += (int64_t)gridDim.x * a.RPB) {
-        for (int e = t; e < a.RPB * W; e += 256) sh[e] = 0u;
+    const int per_row = BYTES ? (a.CP + 1) / 2 : a.CP, rpb = BYTES ? RPB2 : a.RPB;
+    const bool active = t < rpb * per_row;
+    const int rsub = t / per_row, cp = t - rsub * per_row;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < a.N; r0 += (int64_t)gridDim.x * rpb) {
+        for (int e = t; e < rpb * W; e += 256) sh[e] = 0u;
         __syncthreads();
         const int64_t row = r0 + rsub;
         if (active && row < a.N) {
-            float4 k[2];
-            keep8(a, row, cp, k);
+            uint32_t nibs[4];
+            int chunk[4];
+            int n = 2;
+            if (BYTES) {
+                const HgvPhilox ph(a.seed);
+                const uint64_t off = a.offset + (a.offset_dev ? a.offset_dev[0] : 0ull);
+                const uint4 r = keep_bytes16(a, ph, row, cp, off);
+                const uint32_t T8 = a.thresh >> 8;
+                nibs[0] = byte_nibble(r.x, T8); nibs[1] = byte_nibble(r.y, T8); nibs[2] = byte_nibble(r.z, T8); nibs[3] = byte_nibble(r.w, T8);
+                chunk[0] = 2 * cp; chunk[1] = 2 * cp + a.CP; chunk[2] = 2 * cp + 1; chunk[3] = 2 * cp + 1 + a.CP;
+                if (2 * cp + 1 >= a.CP) chunk[2] = chunk[3] = a.CH;          // an odd pair count: the last thread owns one pair
+                n = 4;
+            } else {
+                float4 k[2];
+                keep8(a, row, cp, k);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c0 = (cp + h * a.CP) * 4;
-                if (h == 1 && cp + a.CP >= a.CH) break;
-                uint32_t nib = (k[h].x != 0.f ? 1u : 0u) | (k[h].y != 0.f ? 2u : 0u) | (k[h].z != 0.f ? 4u : 0u) | (k[h].w != 0.f ? 8u : 0u);
+                for (int h = 0; h < 2; ++h) {
+                    nibs[h] = (k[h].x != 0.f ? 1u : 0u) | (k[h].y != 0.f ? 2u : 0u) | (k[h].z != 0.f ? 4u : 0u) | (k[h].w != 0.f ? 8u : 0u);
+                    chunk[h] = cp + h * a.CP;
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (h >= n || chunk[h] >= a.CH) continue;
+                const int c0 = chunk[h] * 4;
+                uint32_t nib = nibs[h];
                 if (c0 + 1 >= a.H) nib |= 2u;
                 if (c0 + 2 >= a.H) nib |= 4u;
                 if (c0 + 3 >= a.H) nib |= 8u;
@@ -905,7 +952,7 @@ __global__ __launch_bounds__(256) void k_dropout_bits(const EpArgs a, uint32_t* 
             }
         }
         __syncthreads();
-        for (int e = t; e < a.RPB * W; e += 256) {
+        for (int e = t; e < rpb * W; e += 256) {
             const int64_t rr = r0 + e / W;
             if (rr < a.N) bits[rr * ldb + (e % W)] = sh[e];
         }
@@ -926,10 +973,13 @@ extern "C" int hgv_dropout_bits(int64_t N, int H, float p, const uint8_t* mask, 
     if (rc != HGV_OK) return rc;
     const int W = (a.CH * 4 + 31) / 32;
     HGV_REQUIRE(ld_bits >= W, HGV_EINVAL, "dropout_bits: %lld words per row, %d needed", (long long)ld_bits, W);
-    HGV_REQUIRE(a.RPB * W <= 512, HGV_EUNSUPPORTED, "dropout_bits: H=%d too wide", H);
-    int64_t g = hgv_cdiv(N, a.RPB);
+    const bool bytes = a.mode == 2 && (a.thresh & 0xffu) == 0u;
+    const int rpb = bytes ? 256 / ((a.CP + 1) / 2) : a.RPB;
+    HGV_REQUIRE(rpb * W <= 1024, HGV_EUNSUPPORTED, "dropout_bits: H=%d too wide", H);
+    int64_t g = hgv_cdiv(N, rpb);
     if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_dropout_bits, dim3((unsigned)g), dim3(256), 0, stream, a, bits, ld_bits, W);
+    if (bytes) hipLaunchKernelGGL(k_dropout_bits<true>, dim3((unsigned)g), dim3(256), 0, stream, a, bits, ld_bits, W, rpb);
+    else hipLaunchKernelGGL(k_dropout_bits<false>, dim3((unsigned)g), dim3(256), 0, stream, a, bits, ld_bits, W, rpb);
     HGV_CHECK_LAUNCH("dropout_bits");
     return HGV_OK;
 }
